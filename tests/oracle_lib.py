@@ -1,0 +1,77 @@
+"""ctypes binding of the CPU restatement (oracle/liboracle.so).  Test-side only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+
+NCOUNTERS = 8
+COUNTER_NAMES = ("N_upd", "B_read", "B_write", "N_src", "L_streamed", "maxlimbs", "K_done", "limb_macs")
+
+
+class _Result(C.Structure):
+    _fields_ = [("n", C.c_int32), ("K", C.c_int32), ("status", C.c_int32),
+                ("lnz", C.c_int64), ("unz", C.c_int64),
+                ("Lp", C.POINTER(C.c_int64)), ("Up", C.POINTER(C.c_int64)),
+                ("Li", C.POINTER(C.c_int32)), ("Ui", C.POINTER(C.c_int32)),
+                ("Llen", C.POINTER(C.c_int32)), ("Ulen", C.POINTER(C.c_int32)),
+                ("Lnl", C.c_int64), ("Unl", C.c_int64),
+                ("Llimbs", C.POINTER(C.c_uint64)), ("Ulimbs", C.POINTER(C.c_uint64)),
+                ("rholen", C.POINTER(C.c_int32)), ("rholimbs", C.POINTER(C.c_uint64)), ("rhonl", C.c_int64),
+                ("pinv", C.POINTER(C.c_int32)),
+                ("counters", C.c_int64 * NCOUNTERS), ("seconds", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port"])
+        _lib = C.CDLL(_SO)
+        _lib.orc_factorize.restype = C.POINTER(_Result)
+        _lib.orc_factorize.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32]
+        _lib.orc_free.argtypes = [C.POINTER(_Result)]
+        _lib.orc_ipge.restype = C.c_int
+    return _lib
+
+
+def _arr(ptr, count, dtype):
+    if count <= 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
+
+
+def factorize(n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, kmax=0, cap=0):
+    """Run the CPU restatement; returns a dict with the canonical factor arrays."""
+    Ap = np.ascontiguousarray(Ap, dtype=np.int64)
+    Ai = np.ascontiguousarray(Ai, dtype=np.int32)
+    Alen = np.ascontiguousarray(Alen, dtype=np.int32)
+    Alimbs = np.ascontiguousarray(Alimbs, dtype=np.uint64)
+    if Alimbs.size == 0:
+        Alimbs = np.zeros(1, dtype=np.uint64)
+    q = np.ascontiguousarray(q, dtype=np.int32)
+    r = lib().orc_factorize(n, Ap.ctypes.data, Ai.ctypes.data, Alen.ctypes.data, Alimbs.ctypes.data,
+                            q.ctypes.data, pivot, float(tol), kmax, cap)
+    if not r:
+        raise MemoryError("orc_factorize")
+    R = r.contents
+    K = R.K
+    out = dict(n=n, K=K, status=R.status, seconds=R.seconds,
+               counters=np.array(list(R.counters), dtype=np.int64))
+    if R.status != -3:
+        out.update(
+            Lp=_arr(R.Lp, K + 1, np.int64), Up=_arr(R.Up, K + 1, np.int64),
+            Li=_arr(R.Li, R.lnz, np.int32), Ui=_arr(R.Ui, R.unz, np.int32),
+            Llen=_arr(R.Llen, R.lnz, np.int32), Ulen=_arr(R.Ulen, R.unz, np.int32),
+            Llimbs=_arr(R.Llimbs, R.Lnl, np.uint64), Ulimbs=_arr(R.Ulimbs, R.Unl, np.uint64),
+            rholen=_arr(R.rholen, K, np.int32), rholimbs=_arr(R.rholimbs, R.rhonl, np.uint64),
+            pinv=_arr(R.pinv, n, np.int32))
+    lib().orc_free(r)
+    return out
