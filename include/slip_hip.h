@@ -1,0 +1,125 @@
+/* slip_hip.h -- C ABI of the MI355X-native REF sparse LU hot path (libslip_hip.so).
+ *
+ * Plain pointers and sizes only: no GMP, no torch, no C++ types.  Big integers
+ * cross this boundary as "limb slabs": per entry a signed limb count
+ * (sign * number of 64-bit limbs, 0 = zero) and the limbs little-endian, back
+ * to back -- the same words GMP keeps behind an mpz_t (_mp_size, _mp_d).
+ *
+ * What each entry point replaces in cjh10644/SLIP_LU (reference file:line):
+ *
+ *   slip_hip_factor_create/run/download  <->  SLIP_LU_factorize
+ *        SLIP_LU/Include/SLIP_LU.h:854-863, SLIP_LU/Source/SLIP_LU_factorize.c:36-314
+ *        (with slip_REF_triangular_solve.c:65-265, slip_reach.c, slip_dfs.c,
+ *         slip_sort_xi.c and slip_get_pivot.c:30-183 inside the column loop)
+ *   slip_hip_options                     <->  SLIP_options.pivot / .tol
+ *        SLIP_LU/Include/SLIP_LU.h:212-223; defaults SLIP_LU_internal.h:136-149
+ *   status codes                         <->  SLIP_info, SLIP_LU.h:160-168
+ *
+ * The GMP-typed drop-in  SLIP_LU_factorize(L,U,A,S,rhos,pinv,option)  built on
+ * top of this ABI is declared in include/SLIP_LU_hip.h (libslip_lu_hip.so).
+ *
+ * Threading: like the reference, one factorisation per handle at a time; the
+ * calls block until the device work is complete.
+ */
+#ifndef SLIP_HIP_H
+#define SLIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SLIP_info values (SLIP_LU.h:160-168), plus one code kept outside them */
+#define SLIP_HIP_OK               0
+#define SLIP_HIP_OUT_OF_MEMORY   (-1)
+#define SLIP_HIP_SINGULAR        (-2)
+#define SLIP_HIP_INCORRECT_INPUT (-3)
+#define SLIP_HIP_DEVICE_ERROR    (-100)   /* HIP runtime failure (no GPU, launch error) */
+
+typedef struct slip_hip_options {
+    int32_t pivot;        /* SLIP_pivot 0..5; default 3 = SLIP_TOL_SMALLEST            */
+    double  tol;          /* SLIP_options.tol; default 1.0                             */
+    int32_t limb_cap;     /* > 0: column-window mode -- stop BEFORE the first column   */
+                          /*      that holds a value of more than limb_cap limbs       */
+    int32_t waves;        /* waves per workgroup (0 = default 16)                      */
+    int64_t lnz_hint;     /* initial capacity of L / U in entries (0 = 4*nnz(A)+n),    */
+    int64_t unz_hint;     /*   cf. SLIP_LU_analysis.lnz/.unz; both grow on demand      */
+} slip_hip_options;
+
+typedef struct slip_hip_info {
+    int32_t n;
+    int32_t K;            /* columns committed so far                                  */
+    int32_t status;       /* SLIP_HIP_* of the last run                                */
+    int32_t window_end;   /* 1: run stopped at the limb cap (column K not committed)   */
+    int64_t lnz, unz;     /* entries of L(:,0:K), U(:,0:K) (pivots in both)            */
+    int64_t l_limbs, u_limbs;
+    /* algorithmic counters of SURVEY.md 8(d), counted by the device */
+    int64_t n_upd, b_read, b_write, n_src, l_streamed, max_limbs;
+    double  kernel_ms;    /* device time of the factorisation kernels of the last run  */
+    int32_t launches;     /* kernel launches of the last run (regrows relaunch)        */
+    int32_t xcap_digits;  /* current stride of the dense scatter vector, 32-bit digits */
+} slip_hip_info;
+
+typedef struct slip_hip_factor slip_hip_factor;
+
+void slip_hip_default_options(slip_hip_options *opt);
+
+/* number of HIP devices visible (0 if none / runtime missing) */
+int slip_hip_device_count(void);
+
+/* Upload A (CSC: Ap[n+1], Ai, per-entry signed limb counts Alen, limbs back to
+ * back in Alimbs, entry order as in the reference's SLIP_sparse: unsorted rows
+ * allowed, a duplicated row keeps the LAST value as slip_get_column.c:22 does)
+ * and the column order q[n] (SLIP_LU_analysis.q).  All inputs are host
+ * pointers; they are copied. */
+int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
+                           const int64_t *Ap, const int32_t *Ai,
+                           const int32_t *Alen, const uint64_t *Alimbs,
+                           const int32_t *q, const slip_hip_options *opt);
+
+/* Forget all columns: back to k = 0 with A and q still resident. */
+int slip_hip_factor_reset(slip_hip_factor *f);
+
+/* Factorise columns [K, kmax) (kmax <= 0 or > n: n).  stream: a hipStream_t
+ * passed as void* (NULL = default stream).  Returns SLIP_HIP_OK when kmax (or
+ * the limb cap) was reached, SLIP_HIP_SINGULAR, SLIP_HIP_OUT_OF_MEMORY, ... */
+int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *stream);
+
+int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *info);
+
+/* Copy the factors to host arrays sized from slip_hip_factor_info:
+ *   Lp[K+1], Li[lnz], Llen[lnz], Llimbs[l_limbs]   (same for U)
+ *   rholen[K], rholimbs[sum |rholen|], pinv[n]
+ * Row indices are ORIGINAL row ids in the reference's entry order
+ * (SLIP_LU_factorize.c:226-263); apply pinv for the final relabel (:293-301).
+ * Any pointer may be NULL to skip that array.  rho_limbs_out: in = capacity in
+ * limbs, out = limbs written. */
+int slip_hip_factor_download(const slip_hip_factor *f,
+                             int64_t *Lp, int32_t *Li, int32_t *Llen, uint64_t *Llimbs,
+                             int64_t *Up, int32_t *Ui, int32_t *Ulen, uint64_t *Ulimbs,
+                             int32_t *rholen, uint64_t *rholimbs, int64_t *rho_limbs_inout,
+                             int32_t *pinv);
+
+void slip_hip_factor_destroy(slip_hip_factor *f);
+
+/* Deterministic synthetic CSC generator of the benchmark configs
+ * (slip_matgen.h): arrays are malloc'ed, release with slip_hip_free. */
+int slip_hip_matgen(int32_t n, double density, int32_t bits, uint64_t seed,
+                    int64_t **Ap, int32_t **Ai, int64_t **Ax);
+void slip_hip_free(void *p);
+
+/* Wave-level limb kernels (wave_bigint.h) run in isolation on the device, one
+ * wavefront per operation, for the parity unit tests.  Operands are arrays of
+ * 32-bit digits.  op: 0 = low product a*b mod B^W, 1 = a+b mod B^W,
+ * 2 = a-b mod B^W, 3 = inverse of odd a modulo B^W (b unused).
+ * out receives nops*W digits. */
+int slip_hip_wave_op_test(int32_t op, int32_t nops, int32_t la, int32_t lb, int32_t W,
+                          const uint32_t *a, const uint32_t *b, uint32_t *out);
+
+const char *slip_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIP_HIP_H */

@@ -26,6 +26,7 @@
  * ExampleMats, and against the algorithmic-byte anchors of SURVEY.md 8(d).
  */
 #include "ref_lu_oracle.h"
+#include "../slip_lu_amd/csrc/slip_matgen.h"
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
@@ -668,3 +669,10 @@ int orc_ipge(int32_t xl, const uint64_t *x, int32_t rjl, const uint64_t *rj,
     bz_clear(&X); bz_clear(&RJ); bz_clear(&Lm); bz_clear(&XJ); bz_clear(&RP); bz_clear(&HM); bz_clear(&HD);
     return rc;
 }
+
+/* the benchmark's synthetic matrix (slip_matgen.h), so oracle-side tests need no HIP library */
+int orc_matgen(int32_t n, double density, int32_t bits, uint64_t seed, int64_t **Ap, int32_t **Ai, int64_t **Ax)
+{
+    return slip_matgen_csc(n, density, bits, seed, Ap, Ai, Ax);
+}
+void orc_free_ptr(void *p) { free(p); }

@@ -60,6 +60,9 @@ int orc_ipge(/* x_i */ int32_t xl, const uint64_t *x, /* rho_j */ int32_t rjl, c
              int32_t hml, const uint64_t *hm, int32_t hdl, const uint64_t *hd,
              int32_t *outlen, uint64_t *out, int32_t outcap);
 
+int orc_matgen(int32_t n, double density, int32_t bits, uint64_t seed, int64_t **Ap, int32_t **Ai, int64_t **Ax);
+void orc_free_ptr(void *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,68 @@
+"""ctypes loader for libslip_hip.so (the HIP product library).
+
+The product path has no CPU fallback: if the in-tree HIP library is missing or
+cannot be loaded this module raises.  The environment variable
+SLIP_HIP_LIBRARY may point to another build of the SAME C ABI (the test-suite
+uses it to load the CPU emulation build of the kernel source, tests/emu).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_SO = os.path.join(_HERE, "csrc", "libslip_hip.so")
+
+
+class Options(C.Structure):
+    _fields_ = [("pivot", C.c_int32), ("tol", C.c_double), ("limb_cap", C.c_int32),
+                ("waves", C.c_int32), ("lnz_hint", C.c_int64), ("unz_hint", C.c_int64)]
+
+
+class Info(C.Structure):
+    _fields_ = [("n", C.c_int32), ("K", C.c_int32), ("status", C.c_int32), ("window_end", C.c_int32),
+                ("lnz", C.c_int64), ("unz", C.c_int64), ("l_limbs", C.c_int64), ("u_limbs", C.c_int64),
+                ("n_upd", C.c_int64), ("b_read", C.c_int64), ("b_write", C.c_int64), ("n_src", C.c_int64),
+                ("l_streamed", C.c_int64), ("max_limbs", C.c_int64),
+                ("kernel_ms", C.c_double), ("launches", C.c_int32), ("xcap_digits", C.c_int32)]
+
+
+EXPORTS = ("slip_hip_default_options", "slip_hip_device_count", "slip_hip_factor_create",
+           "slip_hip_factor_reset", "slip_hip_factor_run", "slip_hip_factor_info",
+           "slip_hip_factor_download", "slip_hip_factor_destroy", "slip_hip_matgen",
+           "slip_hip_free", "slip_hip_wave_op_test", "slip_hip_version")
+
+_libs = {}
+
+
+def library_path():
+    return os.environ.get("SLIP_HIP_LIBRARY", DEFAULT_SO)
+
+
+def load(path=None):
+    """Load (once) and return the C library; raises OSError if it is missing."""
+    path = path or library_path()
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise OSError(f"{path} not found: build the HIP extension first "
+                      "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.slip_hip_default_options.argtypes = [C.POINTER(Options)]
+    lib.slip_hip_default_options.restype = None
+    lib.slip_hip_device_count.restype = C.c_int
+    lib.slip_hip_factor_create.argtypes = [C.POINTER(vp), C.c_int32, vp, vp, vp, vp, vp, C.POINTER(Options)]
+    lib.slip_hip_factor_create.restype = C.c_int
+    lib.slip_hip_factor_reset.argtypes = [vp]
+    lib.slip_hip_factor_run.argtypes = [vp, C.c_int32, vp]
+    lib.slip_hip_factor_info.argtypes = [vp, C.POINTER(Info)]
+    lib.slip_hip_factor_download.argtypes = [vp] + [vp] * 10 + [C.POINTER(C.c_int64), vp]
+    lib.slip_hip_factor_destroy.argtypes = [vp]
+    lib.slip_hip_factor_destroy.restype = None
+    lib.slip_hip_matgen.argtypes = [C.c_int32, C.c_double, C.c_int32, C.c_uint64,
+                                    C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.slip_hip_free.argtypes = [vp]
+    lib.slip_hip_free.restype = None
+    lib.slip_hip_wave_op_test.argtypes = [C.c_int32] * 5 + [vp, vp, vp]
+    lib.slip_hip_version.restype = C.c_char_p
+    _libs[path] = lib
+    return lib

@@ -1,0 +1,137 @@
+"""Python face of the C ABI in include/slip_hip.h (tests, bench, smoke).
+
+Mirrors the reference's expert sequence for the hot path
+(SLIP_LU/Demo/SLIPLU.c:237-256): the column order q comes from the analysis
+step (data to this module), `Factorization.run` is SLIP_LU_factorize.
+All arithmetic happens in the HIP library; this file only marshals arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+STATUS = {0: "SLIP_OK", -1: "SLIP_OUT_OF_MEMORY", -2: "SLIP_SINGULAR",
+          -3: "SLIP_INCORRECT_INPUT", -100: "DEVICE_ERROR"}
+
+
+class SlipError(RuntimeError):
+    def __init__(self, code, where):
+        super().__init__(f"{where}: {STATUS.get(code, code)}")
+        self.code = code
+
+
+def ints_to_slab(values):
+    """int64 numpy array -> (signed limb counts, limbs): |v| < 2^63."""
+    v = np.asarray(values, dtype=np.int64)
+    lens = np.sign(v).astype(np.int32)
+    limbs = np.abs(v[v != 0]).astype(np.uint64)
+    return lens, limbs
+
+
+def matgen(n, density, bits, seed, lib_path=None):
+    """The benchmark's synthetic CSC (slip_matgen.h) -> Ap, Ai, Ax (int64 values)."""
+    lib = _lib.load(lib_path)
+    pAp, pAi, pAx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    rc = lib.slip_hip_matgen(n, density, bits, seed, C.byref(pAp), C.byref(pAi), C.byref(pAx))
+    if rc:
+        raise SlipError(rc, "slip_hip_matgen")
+    Ap = np.ctypeslib.as_array(C.cast(pAp, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+    nnz = int(Ap[n])
+    Ai = np.ctypeslib.as_array(C.cast(pAi, C.POINTER(C.c_int32)), shape=(nnz,)).copy()
+    Ax = np.ctypeslib.as_array(C.cast(pAx, C.POINTER(C.c_int64)), shape=(nnz,)).copy()
+    for p in (pAp, pAi, pAx):
+        lib.slip_hip_free(p)
+    return Ap, Ai, Ax
+
+
+class Factorization:
+    """A resident REF LU factorisation on one GPU (handle of slip_hip_factor_*)."""
+
+    def __init__(self, n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, limb_cap=0, waves=0,
+                 lnz_hint=0, unz_hint=0, lib_path=None):
+        self.lib = _lib.load(lib_path)
+        self.n = int(n)
+        Ap = np.ascontiguousarray(Ap, dtype=np.int64)
+        Ai = np.ascontiguousarray(Ai, dtype=np.int32)
+        Alen = np.ascontiguousarray(Alen, dtype=np.int32)
+        Alimbs = np.ascontiguousarray(Alimbs, dtype=np.uint64)
+        if Alimbs.size == 0:
+            Alimbs = np.zeros(1, dtype=np.uint64)
+        q = np.ascontiguousarray(q, dtype=np.int32)
+        opt = _lib.Options(pivot, tol, limb_cap, waves, lnz_hint, unz_hint)
+        self.h = C.c_void_p()
+        rc = self.lib.slip_hip_factor_create(C.byref(self.h), self.n, Ap.ctypes.data, Ai.ctypes.data,
+                                             Alen.ctypes.data, Alimbs.ctypes.data, q.ctypes.data,
+                                             C.byref(opt))
+        if rc:
+            self.h = None
+            raise SlipError(rc, "slip_hip_factor_create")
+
+    def reset(self):
+        rc = self.lib.slip_hip_factor_reset(self.h)
+        if rc:
+            raise SlipError(rc, "slip_hip_factor_reset")
+
+    def run(self, kmax=0, stream=None, check=True):
+        rc = self.lib.slip_hip_factor_run(self.h, int(kmax), C.c_void_p(stream or 0))
+        if rc and check:
+            raise SlipError(rc, "slip_hip_factor_run")
+        return rc
+
+    def info(self):
+        i = _lib.Info()
+        self.lib.slip_hip_factor_info(self.h, C.byref(i))
+        return {k: getattr(i, k) for k, _ in _lib.Info._fields_}
+
+    def download(self):
+        """Factor arrays in the canonical form the tests compare (original row ids)."""
+        i = self.info()
+        K = i["K"]
+        out = dict(n=self.n, K=K, status=i["status"],
+                   Lp=np.zeros(K + 1, np.int64), Up=np.zeros(K + 1, np.int64),
+                   Li=np.zeros(i["lnz"], np.int32), Ui=np.zeros(i["unz"], np.int32),
+                   Llen=np.zeros(i["lnz"], np.int32), Ulen=np.zeros(i["unz"], np.int32),
+                   Llimbs=np.zeros(max(i["l_limbs"], 1), np.uint64), Ulimbs=np.zeros(max(i["u_limbs"], 1), np.uint64),
+                   rholen=np.zeros(K, np.int32), pinv=np.zeros(self.n, np.int32))
+        # pivots are entries of L: an upper bound of their limbs is l_limbs
+        rho = np.zeros(max(i["l_limbs"], 1), np.uint64)
+        cap = C.c_int64(rho.size)
+        rc = self.lib.slip_hip_factor_download(
+            self.h, out["Lp"].ctypes.data, out["Li"].ctypes.data, out["Llen"].ctypes.data, out["Llimbs"].ctypes.data,
+            out["Up"].ctypes.data, out["Ui"].ctypes.data, out["Ulen"].ctypes.data, out["Ulimbs"].ctypes.data,
+            out["rholen"].ctypes.data, rho.ctypes.data, C.byref(cap), out["pinv"].ctypes.data)
+        if rc:
+            raise SlipError(rc, "slip_hip_factor_download")
+        out["Llimbs"] = out["Llimbs"][:i["l_limbs"]]
+        out["Ulimbs"] = out["Ulimbs"][:i["u_limbs"]]
+        out["rholimbs"] = rho[:cap.value].copy()
+        out["counters"] = np.array([i["n_upd"], i["b_read"], i["b_write"], i["n_src"], i["l_streamed"],
+                                    i["max_limbs"], K, 0], dtype=np.int64)
+        out["info"] = i
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.slip_hip_factor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def factorize(n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, kmax=0, limb_cap=0, waves=0, check=True,
+              lib_path=None):
+    """One-shot SLIP_LU_factorize on the GPU; returns the canonical factor dict."""
+    f = Factorization(n, Ap, Ai, Alen, Alimbs, q, pivot=pivot, tol=tol, limb_cap=limb_cap, waves=waves,
+                      lib_path=lib_path)
+    try:
+        rc = f.run(kmax, check=check)
+        out = f.download()
+        out["status"] = rc
+        return out
+    finally:
+        f.close()

@@ -1,0 +1,102 @@
+/* wave_shim.h -- the few wave64 / workgroup primitives the REF-LU kernels use.
+ *
+ * Device build (hipcc, gfx950): thin inline wrappers over the CDNA4 wave64
+ * intrinsics (__shfl*, __ballot, __syncthreads, LDS/global atomics).
+ *
+ * Host test build (-DSLIP_EMULATE, tests/emu): the same kernel source is run
+ * lane-by-lane on cooperative fibers so that the limb arithmetic, the carry
+ * resolution and the column loop can be unit-tested, and run under
+ * ASan/UBSan, in a container without a GPU.  The emulator is test
+ * infrastructure only; the product library is always the hipcc build.
+ */
+#ifndef SLIP_WAVE_SHIM_H
+#define SLIP_WAVE_SHIM_H
+
+#include <stdint.h>
+
+#define SLIP_WAVE 64
+
+#ifdef SLIP_EMULATE
+/* ------------------------------------------------------------------ */
+#include "fiber_emu.h"          /* tests/emu */
+#define SLIP_DEV static inline
+#define SLIP_SHARED static
+#define SLIP_KERNEL
+
+static inline int slip_tid(void)      { return emu::tid(); }
+static inline int slip_nthreads(void) { return emu::nthreads(); }
+static inline int slip_block(void)    { return emu::block(); }
+static inline int slip_nblocks(void)  { return emu::nblocks(); }
+/* macros, so that the divergence check sees the CALL SITE's line */
+#define slip_block_sync()      emu::block_sync(__LINE__)
+#define slip_wave_sync()       ((void) emu::ballot(0, __LINE__))
+#define slip_ballot(pred)      emu::ballot((pred), __LINE__)
+#define slip_shfl_u32(v, src)  ((uint32_t) emu::shfl((uint64_t)(v), (src), __LINE__))
+#define slip_shfl_u64(v, src)  emu::shfl((uint64_t)(v), (src), __LINE__)
+static inline uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+static inline int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v > o) *p = v; return o; }
+static inline int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
+static inline unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+static inline void slip_fence_block(void) {}
+static inline void slip_fence_device(void) {}
+static inline int slip_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+static inline int slip_ctz32(uint32_t v) { return v ? __builtin_ctz(v) : 32; }
+static inline int slip_clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
+static inline int slip_ctz64(uint64_t v) { return v ? __builtin_ctzll(v) : 64; }
+static inline int slip_popc32(uint32_t v) { return __builtin_popcount(v); }
+static inline int slip_popc64(uint64_t v) { return __builtin_popcountll(v); }
+
+#else
+/* ------------------------------------------------------------------ */
+#include <hip/hip_runtime.h>
+#define SLIP_DEV __device__ __forceinline__
+#define SLIP_SHARED __shared__
+#define SLIP_KERNEL __global__
+
+SLIP_DEV int slip_tid(void)      { return (int) threadIdx.x; }
+SLIP_DEV int slip_nthreads(void) { return (int) blockDim.x; }
+SLIP_DEV int slip_block(void)    { return (int) blockIdx.x; }
+SLIP_DEV int slip_nblocks(void)  { return (int) gridDim.x; }
+SLIP_DEV void slip_block_sync(void) { __syncthreads(); }
+/* orders this wave's LDS/global writes before its lanes' later cross-lane reads */
+SLIP_DEV void slip_wave_sync(void)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+SLIP_DEV uint64_t slip_ballot(int pred) { return (uint64_t) __ballot(pred); }
+SLIP_DEV uint32_t slip_shfl_u32(uint32_t v, int src) { return (uint32_t) __shfl((int) v, src, SLIP_WAVE); }
+SLIP_DEV uint64_t slip_shfl_u64(uint64_t v, int src)
+{
+    uint32_t lo = (uint32_t) __shfl((int)(uint32_t) v, src, SLIP_WAVE);
+    uint32_t hi = (uint32_t) __shfl((int)(uint32_t)(v >> 32), src, SLIP_WAVE);
+    return ((uint64_t) hi << 32) | lo;
+}
+SLIP_DEV uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+SLIP_DEV int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { return atomicMax(p, v); }
+SLIP_DEV int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { return atomicAdd(p, v); }
+SLIP_DEV unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+SLIP_DEV void slip_fence_block(void) { __threadfence_block(); }
+SLIP_DEV void slip_fence_device(void) { __threadfence(); }
+SLIP_DEV int slip_clz32(uint32_t v) { return __clz((int) v); }
+SLIP_DEV int slip_ctz32(uint32_t v) { return v ? __ffs((int) v) - 1 : 32; }
+SLIP_DEV int slip_clz64(uint64_t v) { return __clzll((long long) v); }
+SLIP_DEV int slip_ctz64(uint64_t v) { return v ? __ffsll((unsigned long long) v) - 1 : 64; }
+SLIP_DEV int slip_popc32(uint32_t v) { return __popc(v); }
+SLIP_DEV int slip_popc64(uint64_t v) { return __popcll(v); }
+#endif
+
+SLIP_DEV int slip_lane(void)   { return slip_tid() & (SLIP_WAVE - 1); }
+SLIP_DEV int slip_wave(void)   { return slip_tid() >> 6; }
+SLIP_DEV int slip_nwaves(void) { return slip_nthreads() >> 6; }
+
+/* value of lane (lane-d), own value for lanes < d */
+SLIP_DEV uint32_t slip_shfl_up_u32(uint32_t v, int d)
+{
+    int l = slip_lane(), s = l - d;
+    uint32_t r = slip_shfl_u32(v, s < 0 ? l : s);
+    return r;
+}
+
+#endif /* SLIP_WAVE_SHIM_H */

@@ -39,6 +39,9 @@ def lib():
                                        C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32]
         _lib.orc_free.argtypes = [C.POINTER(_Result)]
         _lib.orc_ipge.restype = C.c_int
+        _lib.orc_matgen.argtypes = [C.c_int32, C.c_double, C.c_int32, C.c_uint64,
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        _lib.orc_free_ptr.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -75,3 +78,18 @@ def factorize(n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, kmax=0, cap=0):
             pinv=_arr(R.pinv, n, np.int32))
     lib().orc_free(r)
     return out
+
+
+def matgen(n, density, bits, seed):
+    """slip_matgen.h through the oracle library -> Ap, Ai, Ax (int64 values)."""
+    L = lib()
+    pAp, pAi, pAx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    if L.orc_matgen(n, density, bits, seed, C.byref(pAp), C.byref(pAi), C.byref(pAx)):
+        raise MemoryError("orc_matgen")
+    Ap = np.ctypeslib.as_array(C.cast(pAp, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+    nnz = int(Ap[n])
+    Ai = np.ctypeslib.as_array(C.cast(pAi, C.POINTER(C.c_int32)), shape=(nnz,)).copy()
+    Ax = np.ctypeslib.as_array(C.cast(pAx, C.POINTER(C.c_int64)), shape=(nnz,)).copy()
+    for p in (pAp, pAi, pAx):
+        L.orc_free_ptr(p)
+    return Ap, Ai, Ax
