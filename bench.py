@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline benchmark on MI355X.
+
+Metric (BASELINE.json): L+U nonzeros/sec on the random n=100k, 0.1%-dense integer CSC
+(configs[3], "limb cap 64"), plus achieved HBM GB/s against the gfx950 peak.
+
+One *step* = one pass of the hot path over the workload: the left-looking REF LU column loop
+(SLIP_LU_factorize) over the column window [0, K) of the matrix, K = the first column that
+holds a value of more than 64 limbs (the full factorisation is infeasible for
+anyone, so CPU and GPU run the same K).  Inputs (A, q) are resident in HBM before the timed
+region; every step starts from column 0 (device-side reset included in the timing).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path has no exploitable
+elimination-tree subtrees on this matrix class (multi-GPU), so ranks are
+independent replicas of the same workload -- weak scaling, no data-path collective; RCCL is
+used only for the barrier and the max-over-ranks of the step time.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+WORKLOAD = dict(n=100000, density=0.001, bits=16, seed=1, limb_cap=64, golden="C4_n100k_c64")
+
+
+def load_q(name):
+    import slabfile
+    return slabfile.load(os.path.join(ROOT, "tests", "golden", name + ".slab.gz"))["q"]
+
+
+def cpu_baseline(expect_K, expect_nnz):
+    """The reference's own column loop on this host's cores (1 core: it is single-threaded),
+    on the same window.  Prefers the compiled reference (oracle/_ref), else the C restatement."""
+    w = WORKLOAD
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    sample = f"same workload: columns [0,{expect_K}) of gen:{w['n']},{w['density']},{w['bits']},{w['seed']}"
+    if os.path.exists(drv):
+        try:
+            import slabfile
+            out = os.path.join("/tmp", f"slip_ref_{os.getpid()}.slab")
+            spec = f"gen:{w['n']},{w['density']},{w['bits']},{w['seed']}"
+            subprocess.run([drv, "window", spec, out, "0", str(w["limb_cap"])], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            d = slabfile.load(out)
+            os.unlink(out)
+            K = int(d["K"][0])
+            nnz = len(d["Li"]) + len(d["Ui"]) - K
+            if K == expect_K and nnz == expect_nnz:
+                t = float(d["timing"][0])
+                return dict(value=nnz / t, unit="L+U nonzeros/s", cores=1, kind="reference",
+                            seconds=t, sample=sample + " (reference's COLAMD order, compiled reference + GMP)")
+        except Exception as e:                       # fall through to the port
+            print(f"[bench] reference baseline unavailable: {e}", file=sys.stderr)
+    import numpy as np
+    import oracle_lib
+    Ap, Ai, Ax = oracle_lib.matgen(w["n"], w["density"], w["bits"], w["seed"])
+    r = oracle_lib.factorize(w["n"], Ap, Ai, np.sign(Ax).astype(np.int32), np.abs(Ax).astype(np.uint64),
+                             load_q(w["golden"]), cap=w["limb_cap"])
+    nnz = len(r["Li"]) + len(r["Ui"]) - r["K"]
+    return dict(value=nnz / r["seconds"], unit="L+U nonzeros/s", cores=1, kind="port",
+                seconds=r["seconds"], sample=sample + " (CPU restatement oracle/ref_lu_oracle.c)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import slip_lu_amd as sl
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    w = WORKLOAD
+    Ap, Ai, Ax = sl.matgen(w["n"], w["density"], w["bits"], w["seed"])
+    Alen, Alimbs = sl.ints_to_slab(Ax)
+    q = load_q(w["golden"])
+    f = sl.Factorization(w["n"], Ap, Ai, Alen, Alimbs, q, limb_cap=w["limb_cap"])
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        f.reset()
+        f.run(0, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        step()
+        kernel_ms += f.info()["kernel_ms"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = f.info()
+    K = info["K"]
+    nnz = info["lnz"] + info["unz"] - K
+    # parity guard: the run being timed must be the reference's window (golden index)
+    idx = {e["name"]: e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "index.json")))}[w["golden"]]
+    assert K == idx["K"] and nnz == idx["lnz"] + idx["unz"] - idx["K"], "benchmark run differs from the reference window"
+    assert info["b_read"] == idx["counters"]["B_read"] and info["b_write"] == idx["counters"]["B_write"]
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    kms = kernel_ms / args.steps                       # HIP-event time of the column-loop kernel per launch
+    value = world * nnz / (elapsed / args.steps)
+    achieved = info["b_read"] / (kms * 1e-3) / 1e9     # GB/s, algorithmic reads
+    out = {
+        "metric": "L+U nonzeros/sec on random n=100k 0.1%-dense CSC; achieved HBM GB/s vs peak",
+        "value": value, "unit": "L+U nonzeros/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 limbs (u32 digits on device)", "data": "synthetic",
+        "config": {"workload": "C4: random CSC n=100000 density=0.001 |a|<2^16 seed=1, COLAMD order (fixture), "
+                               "default pivoting, column window until a value exceeds 64 limbs",
+                   "columns": K, "lu_nnz": nnz, "n_upd": info["n_upd"], "max_limbs": info["max_limbs"],
+                   "parallelism": "replicas" if world > 1 else "1 GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "slip_factor_kernel", "kernel_ms_per_launch": kms,
+                     "algorithmic_read_bytes": info["b_read"], "algorithmic_write_bytes": info["b_write"],
+                     "achieved_read_plus_write": (info["b_read"] + info["b_write"]) / (kms * 1e-3) / 1e9},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(K, nnz)
+    f.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,8 @@ class Info(C.Structure):
 EXPORTS = ("slip_hip_default_options", "slip_hip_device_count", "slip_hip_factor_create",
            "slip_hip_factor_reset", "slip_hip_factor_run", "slip_hip_factor_info",
            "slip_hip_factor_download", "slip_hip_factor_destroy", "slip_hip_matgen",
-           "slip_hip_free", "slip_hip_wave_op_test", "slip_hip_version")
+           "slip_hip_free", "slip_hip_wave_op_test", "slip_hip_version",
+           "slip_hip_factor_phase_cycles")
 
 _libs = {}
 

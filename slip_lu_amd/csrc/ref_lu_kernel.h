@@ -62,7 +62,17 @@ typedef struct SlipDev {
     uint32_t *gbitmap; int32_t bm_words, bitmap_in_lds;
     /* algorithmic counters, committed columns only */
     unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig;
+    /* diagnostic builds only (-DSLIP_PROFILE_PHASES): shader cycles per phase, thread 0 */
+    unsigned long long prof[12];
 } SlipDev;
+
+#if defined(SLIP_PROFILE_PHASES) && !defined(SLIP_EMULATE)
+#define SLIP_STAMP(slot) do { if (tid == 0) { unsigned long long now_ = clock64(); S->prof[slot] += now_ - t_prev_; t_prev_ = now_; } } while (0)
+#define SLIP_STAMP_INIT() unsigned long long t_prev_ = clock64()
+#else
+#define SLIP_STAMP(slot) do { } while (0)
+#define SLIP_STAMP_INIT() do { } while (0)
+#endif
 
 /* LDS layout in 32-bit words */
 #define SLIP_LDS_VARS      0        /* 64 words of workgroup-shared scalars */
@@ -303,6 +313,7 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
     dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
     unsigned long long c_read = 0, c_upd = 0, c_src = 0, c_str = 0;
 
+    SLIP_STAMP_INIT();
     /* ---- phase 0: clear the pattern bitmap ---- */
     for (int w = tid; w < S->bm_words; w += T) bm[w] = 0;
     if (tid == 0) { sv[SV_ERR] = 0; }
@@ -325,6 +336,7 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
     }
     slip_block_sync();
     if (sv[SV_ERR]) return SLIPDEV_GROW_X;
+    SLIP_STAMP(0);
 
     /* ---- phase 2: ascending sweep over the pivotal part of the pattern ---- */
     int cur = -1;
@@ -369,6 +381,7 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
     }
     slip_block_sync();
     if (sv[SV_ERR]) return SLIPDEV_GROW_X;
+    SLIP_STAMP(1);
 
     /* ---- phase 3: read the bitmap in order = the sorted pattern (slip_sort_xi.c) ---- */
     const int nwords = S->bm_words;
@@ -394,6 +407,7 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
     }
     const int npat = (int)(tot >> 32), nU = (int)(tot & 0xFFFFFFFFu), nL = npat - nU;
     slip_block_sync();
+    SLIP_STAMP(2);
 
     /* ---- phase 4: history update of the non-pivotal rows to level k-1 (:248-257) ---- */
     if (k >= 1) {
@@ -405,6 +419,7 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
     }
     slip_block_sync();
     if (sv[SV_ERR]) return SLIPDEV_GROW_X;
+    SLIP_STAMP(3);
 
     /* ---- phase 5: column-window cap, then the pivot search ---- */
     {
@@ -484,6 +499,7 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
         }
     }
     const int pivpos = S->pinv[pivrow];               /* pre-swap position, >= k */
+    SLIP_STAMP(4);
 
     /* ---- phase 6: append U(:,k) and L(:,k) (SLIP_LU_factorize.c:226-263) ---- */
     /* U(:,k): pattern rows below k in order, then the pivot.  L(:,k): rows at or above k in order. */
@@ -522,6 +538,7 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
         }
     }
     slip_block_sync();
+    SLIP_STAMP(5);
     /* limbs: one wave per entry, coalesced */
     for (int t = wave; t < nUe + nL; t += nw) {
         const int isU = t < nUe;
@@ -531,6 +548,7 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
         wb_copy_pad(dst, S->xd + (int64_t) r * S->xcap, slip_abs(S->xlen[r]));
     }
     slip_block_sync();
+    SLIP_STAMP(6);
     /* pivot bookkeeping (slip_get_pivot.c:164-182); wave 0 */
     if (wave == 0) {
         const int64_t pat_at = S->Lnz + (int64_t) best;       /* valid only when pivrow was the searched best */
@@ -562,6 +580,7 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
     }
     *t_read += c_read; *t_upd += c_upd; *t_src += c_src; *t_str += c_str;
     slip_block_sync();
+    SLIP_STAMP(7);
     return SLIPDEV_OK;
 }
 

@@ -164,6 +164,7 @@ extern "C" int slip_hip_factor_reset(slip_hip_factor *f)
     h->Lnz = h->Lnl = h->Unz = h->Unl = 0;
     h->k_next = 0; h->status = 0; h->status_k = 0;
     h->c_upd = h->c_read = h->c_write = h->c_src = h->c_streamed = h->c_maxdig = 0;
+    memset(h->prof, 0, sizeof h->prof);
     f->last_status = 0; f->window_end = 0; f->kernel_ms = 0; f->launches = 0;
     return SLIP_HIP_OK;
 }
@@ -362,6 +363,14 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
     }
     f->last_status = rc;
     return rc;
+}
+
+/* diagnostic: per-phase shader cycles of the last run (zeros unless built with -DSLIP_PROFILE_PHASES) */
+extern "C" int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out12)
+{
+    if (!f || !out12) return SLIP_HIP_INCORRECT_INPUT;
+    for (int i = 0; i < 12; i++) out12[i] = f->h.prof[i];
+    return SLIP_HIP_OK;
 }
 
 extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)

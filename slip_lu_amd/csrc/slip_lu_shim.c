@@ -1,0 +1,150 @@
+/* slip_lu_shim.c -- libslip_lu_hip.so: the reference's SLIP_LU_factorize entry point
+ * (SLIP_LU/Include/SLIP_LU.h:854-863) served by the HIP path.
+ *
+ * Host C only: converts the caller's mpz_t CSC into the limb-slab arrays of
+ * include/slip_hip.h, runs the factorisation on the GPU, and materialises L, U,
+ * rhos, pinv exactly as the reference hands them back
+ * (SLIP_LU/Source/SLIP_LU_factorize.c:170-301):
+ *   - L, U arrive from SLIP_create_sparse() (p = i = x = NULL) and leave owning
+ *     p[n+1], i[nz], x[nz] with nzmax == nz (slip_sparse_collapse.c:28-32);
+ *   - every x[p] is a genuine mpz_t initialised with mpz_init2(bits+2) and set
+ *     through GMP, so SLIP_delete_sparse -> mpz_clear frees it with whatever
+ *     allocator the caller installed (SLIP_initialize_expert.c:95);
+ *   - L->i, U->i hold the PERMUTED row positions (the relabel of :293-301);
+ *   - rhos[k] (already mpz_init-ed by the caller) is assigned with GMP;
+ *   - errors: SLIP_INCORRECT_INPUT for missing arguments (:48-52), SLIP_SINGULAR
+ *     (slip_get_smallest_pivot.c:93-96), SLIP_OUT_OF_MEMORY; a HIP failure maps
+ *     to SLIP_OUT_OF_MEMORY (there is no CPU fallback).
+ * Index arrays come from SLIP_calloc when the reference library is linked in
+ * (so a MATLAB-aware allocator is honoured), from calloc otherwise.
+ */
+#include "../../include/SLIP_LU_hip.h"
+#include "../../include/slip_hip.h"
+#include <stdlib.h>
+#include <string.h>
+
+extern void *SLIP_calloc(size_t n, size_t size) __attribute__((weak));
+
+static void *shim_calloc(size_t n, size_t size)
+{
+    if (n == 0) n = 1;
+    return SLIP_calloc ? SLIP_calloc(n, size) : calloc(n, size);
+}
+
+static void set_from_limbs(mpz_t z, int32_t slen, const uint64_t *limbs)
+{
+    int32_t l = slen < 0 ? -slen : slen;
+    if (l == 0) { mpz_set_ui(z, 0); return; }
+    mpz_import(z, (size_t) l, -1, 8, 0, 0, limbs);
+    if (slen < 0) mpz_neg(z, z);
+}
+
+/* fill a SLIP_sparse from slab arrays; returns SLIP_OK or SLIP_OUT_OF_MEMORY */
+static SLIP_info build_factor(SLIP_sparse *M, int32_t n, int64_t nz, const int64_t *p, const int32_t *ids,
+                              const int32_t *len, const uint64_t *limbs, const int32_t *pinv)
+{
+    M->m = n; M->n = n; M->nz = (int32_t) nz; M->nzmax = (int32_t) nz;
+    M->p = (int32_t *) shim_calloc((size_t) n + 1, sizeof(int32_t));
+    M->i = (int32_t *) shim_calloc((size_t) nz, sizeof(int32_t));
+    M->x = (mpz_t *) shim_calloc((size_t) nz, sizeof(mpz_t));
+    if (!M->p || !M->i || !M->x) return SLIP_OUT_OF_MEMORY;
+    for (int32_t k = 0; k <= n; k++) M->p[k] = (int32_t) p[k];
+    int64_t o = 0;
+    for (int64_t t = 0; t < nz; t++) {
+        int32_t l = len[t] < 0 ? -len[t] : len[t];
+        size_t bits = 0;
+        if (l) bits = 64 * (size_t)(l - 1) + (64 - (size_t) __builtin_clzll(limbs[o + l - 1]));
+        mpz_init2(M->x[t], (bits ? bits : 1) + 2);           /* SLIP_LU_factorize.c:239-241 */
+        set_from_limbs(M->x[t], len[t], limbs + o);
+        M->i[t] = pinv[ids[t]];                              /* :293-301 */
+        o += l;
+    }
+    return SLIP_OK;
+}
+
+SLIP_info SLIP_hip_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, SLIP_LU_analysis *S,
+                                mpz_t *rhos, int32_t *pinv, SLIP_options *option)
+{
+    if (!A || !L || !U || !S || !rhos || !pinv || !option || !A->p || !A->x || !A->i || !S->q)
+        return SLIP_INCORRECT_INPUT;
+    const int32_t n = A->n;
+    if (n <= 0 || A->p[n] < 1) return SLIP_INCORRECT_INPUT;
+    const int64_t annz = A->p[n];
+    SLIP_info ret = SLIP_OUT_OF_MEMORY;
+    slip_hip_factor *f = NULL;
+    int64_t *Ap = NULL, *Lp = NULL, *Up = NULL;
+    int32_t *Alen = NULL, *Li = NULL, *Ui = NULL, *Llen = NULL, *Ulen = NULL, *rholen = NULL;
+    uint64_t *Alimbs = NULL, *Llimbs = NULL, *Ulimbs = NULL, *rholimbs = NULL;
+    slip_hip_info info;
+    slip_hip_options opt;
+    int rc;
+
+    /* ---- A: mpz_t -> limb slab ---- */
+    int64_t nl = 0;
+    for (int64_t t = 0; t < annz; t++) nl += (int64_t) mpz_size(A->x[t]);
+    Ap = (int64_t *) malloc(((size_t) n + 1) * 8);
+    Alen = (int32_t *) malloc((size_t) annz * 4);
+    Alimbs = (uint64_t *) malloc((size_t)(nl ? nl : 1) * 8);
+    if (!Ap || !Alen || !Alimbs) goto done;
+    for (int32_t j = 0; j <= n; j++) Ap[j] = A->p[j];
+    {
+        int64_t o = 0;
+        for (int64_t t = 0; t < annz; t++) {
+            size_t l = mpz_size(A->x[t]);
+            if (l) memcpy(Alimbs + o, mpz_limbs_read(A->x[t]), l * 8);
+            Alen[t] = mpz_sgn(A->x[t]) < 0 ? -(int32_t) l : (int32_t) l;
+            o += (int64_t) l;
+        }
+    }
+
+    /* ---- factorise on the GPU ---- */
+    slip_hip_default_options(&opt);
+    opt.pivot = (int32_t) option->pivot;
+    opt.tol = option->tol;
+    opt.lnz_hint = S->lnz; opt.unz_hint = S->unz;
+    rc = slip_hip_factor_create(&f, n, Ap, A->i, Alen, Alimbs, S->q, &opt);
+    if (rc == SLIP_HIP_OK) rc = slip_hip_factor_run(f, 0, NULL);
+    if (rc != SLIP_HIP_OK) {
+        ret = rc == SLIP_HIP_SINGULAR ? SLIP_SINGULAR
+            : rc == SLIP_HIP_INCORRECT_INPUT ? SLIP_INCORRECT_INPUT : SLIP_OUT_OF_MEMORY;
+        goto done;
+    }
+    slip_hip_factor_info(f, &info);
+    if (info.lnz > INT32_MAX || info.unz > INT32_MAX) goto done;      /* int32 CSC of the reference */
+    Lp = (int64_t *) malloc(((size_t) n + 1) * 8); Up = (int64_t *) malloc(((size_t) n + 1) * 8);
+    Li = (int32_t *) malloc((size_t) info.lnz * 4); Ui = (int32_t *) malloc((size_t) info.unz * 4);
+    Llen = (int32_t *) malloc((size_t) info.lnz * 4); Ulen = (int32_t *) malloc((size_t) info.unz * 4);
+    Llimbs = (uint64_t *) malloc((size_t)(info.l_limbs ? info.l_limbs : 1) * 8);
+    Ulimbs = (uint64_t *) malloc((size_t)(info.u_limbs ? info.u_limbs : 1) * 8);
+    rholen = (int32_t *) malloc((size_t) n * 4);
+    rholimbs = (uint64_t *) malloc((size_t)(info.l_limbs ? info.l_limbs : 1) * 8);
+    if (!Lp || !Up || !Li || !Ui || !Llen || !Ulen || !Llimbs || !Ulimbs || !rholen || !rholimbs) goto done;
+    {
+        int64_t rcap = info.l_limbs;
+        if (slip_hip_factor_download(f, Lp, Li, Llen, Llimbs, Up, Ui, Ulen, Ulimbs, rholen, rholimbs, &rcap, pinv) != SLIP_HIP_OK)
+            goto done;
+    }
+
+    /* ---- hand the results over the way the reference does ---- */
+    ret = build_factor(L, n, info.lnz, Lp, Li, Llen, Llimbs, pinv);
+    if (ret == SLIP_OK) ret = build_factor(U, n, info.unz, Up, Ui, Ulen, Ulimbs, pinv);
+    if (ret == SLIP_OK) {
+        int64_t o = 0;
+        for (int32_t k = 0; k < n; k++) {
+            set_from_limbs(rhos[k], rholen[k], rholimbs + o);
+            o += rholen[k] < 0 ? -rholen[k] : rholen[k];
+        }
+    }
+done:
+    if (f) slip_hip_factor_destroy(f);
+    free(Ap); free(Alen); free(Alimbs); free(Lp); free(Up); free(Li); free(Ui); free(Llen); free(Ulen);
+    free(Llimbs); free(Ulimbs); free(rholen); free(rholimbs);
+    return ret;
+}
+
+/* the reference's symbol: interposes when this library is linked ahead of libsliplu */
+SLIP_info SLIP_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, SLIP_LU_analysis *S,
+                            mpz_t *rhos, int32_t *pinv, SLIP_options *option)
+{
+    return SLIP_hip_LU_factorize(L, U, A, S, rhos, pinv, option);
+}
