@@ -12,23 +12,27 @@
  *    over a bitmap indexed by pivot position (LDS): the next source is the next
  *    set bit below k; streaming that source's L column marks its rows.  The
  *    bitmap, read in order, IS the reference's sorted pattern xi[top..n).
- *  - One wavefront per IPGE update (target nonzero); the rows of a source's L
- *    column are dealt round-robin to the waves of the workgroup; indices and
- *    limbs stream coalesced from HBM, the big-integer intermediates live in LDS.
- *  - Exact divisions by pivots are 2-adic (wave_bigint.h); pivot inverses are
- *    computed lazily per pivot and cached in HBM.
+ *  - A source's L column is streamed coalesced, one entry per LANE: index,
+ *    packed entry record, row state.  Updates whose operands fit one 64-bit
+ *    limb are finished right there in the lane with 128-bit modular
+ *    arithmetic; the others are queued in LDS and done one per WAVEFRONT with
+ *    the limb-parallel primitives of wave_bigint.h (intermediates in LDS).
+ *  - Exact divisions by pivots are 2-adic; pivot inverses are computed lazily
+ *    per pivot and cached in HBM (the 64-bit inverse eagerly, in the pivot record).
  *  - Pivot search, row-permutation swap and the append of U(:,k), L(:,k) to the
  *    limb slabs happen on the device; the host only launches and grows buffers.
  *
  * Values are sign-magnitude: a signed digit count (32-bit digits) plus the
- * magnitude; slabs hold whole 64-bit limbs (odd digit counts are zero padded).
+ * magnitude; all stores are padded to whole 64-bit limbs.
  */
 #ifndef SLIP_REF_LU_KERNEL_H
 #define SLIP_REF_LU_KERNEL_H
 
 #include "wave_bigint.h"
 
-/* status of a launch (SlipDev.status) */
+typedef unsigned __int128 slip_u128;
+
+/* status of a launch (SlipState.status) */
 enum {
     SLIPDEV_OK = 0,          /* reached k_stop                                      */
     SLIPDEV_SINGULAR = 1,    /* no eligible nonzero pivot in column status_k        */
@@ -38,36 +42,44 @@ enum {
     SLIPDEV_WINDOW_END = 5   /* column status_k holds a value above limb_cap         */
 };
 
-typedef struct SlipDev {
+/* state of one row of the dense scatter vector x */
+typedef struct { int32_t len, h, bits, pad; } SlipRow;            /* signed digits, history, bit length */
+/* one stored entry of L or U: where its limbs are, how long, how many bits */
+typedef struct { int64_t off; int32_t len, bits; } SlipEnt;       /* off in 64-bit limbs */
+/* one pivot rho[k] (= the pivot entry of L(:,k)) */
+typedef struct {
+    int64_t off; int32_t len, bits;          /* limbs in the L slab */
+    uint64_t lo; int32_t ctz, invlen;        /* low limb; trailing zero bits; cached inverse digits */
+    uint64_t inv64, pad;                     /* inverse of the odd part modulo 2^64 (one-limb pivots) */
+} SlipPiv;
+
+/* immutable during a launch: passed by value (kernarg -> scalar loads) */
+typedef struct SlipParams {
     int32_t n, pivot_scheme, limb_cap, tol_mode;    /* tol_mode 0: tol <= 0          */
-    uint64_t tol_m; int32_t tol_e, pad0;            /* tol = tol_m * 2^tol_e         */
-    int32_t k_next, k_stop, status, status_k;
-    /* A (CSC, duplicate-free columns) and the column order */
+    uint64_t tol_m; int32_t tol_e, k_stop;          /* tol = tol_m * 2^tol_e         */
     const int64_t *Ap; const int32_t *Ai; const int32_t *Alen; const int64_t *Aoff;
     const uint64_t *Alimbs; const int32_t *q;
-    /* row permutation and history */
-    int32_t *pinv, *row_perm, *h;
-    /* dense scatter vector x: row i at xd[i*xcap], signed digit count xlen[i] */
-    uint32_t *xd; int32_t *xlen; int32_t xcap, invcap;
-    /* pivots: rho[k] is the pivot entry of L(:,k) in the L slab */
-    int64_t *rho_off; int32_t *rho_len, *rho_bits, *rho_ctz;
-    uint32_t *invd; int32_t *invlen;
-    /* factors under construction */
-    int64_t *Lp; int32_t *Li, *Llen; int64_t *Loff; uint64_t *Llimbs; int64_t Lcap_nz, Lcap_nl, Lnz, Lnl;
-    int64_t *Up; int32_t *Ui, *Ulen; int64_t *Uoff; uint64_t *Ulimbs; int64_t Ucap_nz, Ucap_nl, Unz, Unl;
-    /* pattern of the current column (pivot positions, ascending) */
-    int32_t *pat;
-    /* scratch: 3 buffers of wcap digits per wave; LDS unless it does not fit */
-    uint32_t *gscratch; int32_t wcap, scratch_in_lds;
-    uint32_t *gbitmap; int32_t bm_words, bitmap_in_lds;
-    /* algorithmic counters, committed columns only */
+    int32_t *pinv, *row_perm;
+    SlipRow *xrow; uint32_t *xd;                    /* row i's digits at xd[i*xcap]  */
+    SlipPiv *piv; uint32_t *invd;                   /* pivot p's inverse at invd[p*invcap] */
+    int32_t xcap, invcap, wcap, bm_words;
+    int64_t *Lp; int32_t *Li; SlipEnt *Le; uint64_t *Llimbs; int64_t Lcap_nz, Lcap_nl;
+    int64_t *Up; int32_t *Ui; SlipEnt *Ue; uint64_t *Ulimbs; int64_t Ucap_nz, Ucap_nl;
+    int32_t *pat;                                   /* pattern of the column: pivot positions, ascending */
+    uint32_t *gscratch, *gbitmap;                   /* used when LDS does not hold them */
+} SlipParams;
+
+/* mutable across launches */
+typedef struct SlipState {
+    int32_t k_next, status, status_k, pad;
+    int64_t Lnz, Lnl, Unz, Unl;
     unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig;
-    /* diagnostic builds only (-DSLIP_PROFILE_PHASES): shader cycles per phase, thread 0 */
-    unsigned long long prof[12];
-} SlipDev;
+    unsigned long long prof[12];                    /* -DSLIP_PROFILE_PHASES builds only */
+} SlipState;
 
 #if defined(SLIP_PROFILE_PHASES) && !defined(SLIP_EMULATE)
-#define SLIP_STAMP(slot) do { if (tid == 0) { unsigned long long now_ = clock64(); S->prof[slot] += now_ - t_prev_; t_prev_ = now_; } } while (0)
+#define SLIP_STAMP(slot) do { if (tid == 0) { unsigned long long now_ = clock64(); st->prof[slot] += now_ - t_prev_; t_prev_ = now_; } } while (0)
+#define SLIP_PROFILING 1
 #define SLIP_STAMP_INIT() unsigned long long t_prev_ = clock64()
 #else
 #define SLIP_STAMP(slot) do { } while (0)
@@ -75,36 +87,61 @@ typedef struct SlipDev {
 #endif
 
 /* LDS layout in 32-bit words */
-#define SLIP_LDS_VARS      0        /* 64 words of workgroup-shared scalars */
-#define SLIP_LDS_SCAN      64       /* 64 words: per-wave partial sums (u64) */
-#define SLIP_LDS_BITMAP    128
+#define SLIP_LDS_VARS      0        /* 64 words of workgroup-shared scalars          */
+#define SLIP_LDS_SCAN      64       /* 128 words: per-wave partials of scans/reductions */
+#define SLIP_LDS_WORK      192      /* 2 work lists of SLIP_WORK_CAP (m, i) pairs     */
+#define SLIP_WORK_CAP      1024
+#define SLIP_LDS_BITMAP    (SLIP_LDS_WORK + 2 * 2 * SLIP_WORK_CAP)
 
-enum { SV_BEST = 0 /* 16 */, SV_ERR = 16, SV_PIVROW = 17, SV_PIVT = 18, SV_NU = 19, SV_NL = 20,
-       SV_MAXDIG = 21, SV_DIAGOK = 22 };
+enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_LISTN = 6,
+       SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14 };
 
-/* ------------------------------------------------------------------ */
+SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
+SLIP_DEV int slip_abs(int32_t v) { return v < 0 ? -v : v; }
+SLIP_DEV int slip_limbs(int32_t slen) { return (slip_abs(slen) + 1) >> 1; }
+
 SLIP_DEV uint64_t slip_shfl_up_u64(uint64_t v, int d)
 {
     int l = slip_lane(), s = l - d;
     return slip_shfl_u64(v, s < 0 ? l : s);
 }
 
-/* exclusive prefix sum of v over the workgroup's threads; *total = sum */
-SLIP_DEV uint64_t slip_block_scan(uint64_t v, uint64_t *tmp, uint64_t *total)
+/* exclusive prefix sums of two values over the workgroup's threads; totals returned */
+SLIP_DEV void slip_block_scan2(uint64_t a, uint64_t b, uint64_t *tmp, uint64_t *ea, uint64_t *eb,
+                               uint64_t *ta, uint64_t *tb)
 {
     const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
-    uint64_t inc = v;
+    uint64_t ia = a, ib = b;
     for (int d = 1; d < SLIP_WAVE; d <<= 1) {
-        uint64_t t = slip_shfl_up_u64(inc, d);
-        if (lane >= d) inc += t;
+        uint64_t x = slip_shfl_up_u64(ia, d), y = slip_shfl_up_u64(ib, d);
+        if (lane >= d) { ia += x; ib += y; }
     }
-    if (lane == SLIP_WAVE - 1) tmp[wave] = inc;
+    if (lane == SLIP_WAVE - 1) { tmp[2 * wave] = ia; tmp[2 * wave + 1] = ib; }
     slip_block_sync();
-    uint64_t base = 0, tot = 0;
-    for (int w = 0; w < nw; w++) { uint64_t t = tmp[w]; if (w < wave) base += t; tot += t; }
+    uint64_t ba = 0, bb = 0, sa = 0, sb = 0;
+    for (int w = 0; w < nw; w++) {
+        uint64_t x = tmp[2 * w], y = tmp[2 * w + 1];
+        if (w < wave) { ba += x; bb += y; }
+        sa += x; sb += y;
+    }
     slip_block_sync();
-    *total = tot;
-    return base + inc - v;
+    *ea = ba + ia - a; *eb = bb + ib - b; *ta = sa; *tb = sb;
+}
+
+/* workgroup minimum of a 64-bit key (all threads get it) */
+SLIP_DEV uint64_t slip_block_min_u64(uint64_t v, uint64_t *tmp)
+{
+    const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint64_t o = slip_shfl_u64(v, lane ^ d);
+        if (o < v) v = o;
+    }
+    if (lane == 0) tmp[wave] = v;
+    slip_block_sync();
+    uint64_t r = tmp[0];
+    for (int w = 1; w < nw; w++) { uint64_t t = tmp[w]; if (t < r) r = t; }
+    slip_block_sync();
+    return r;
 }
 
 /* next set bit of the position bitmap in [from, limit), or -1 (wave-cooperative) */
@@ -131,130 +168,174 @@ SLIP_DEV int slip_bitmap_next(const uint32_t *bm, int from, int limit)
     return -1;
 }
 
-SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
-SLIP_DEV int slip_abs(int32_t v) { return v < 0 ? -v : v; }
+SLIP_DEV const dig_t *slip_piv_digits(const SlipParams &P, const SlipPiv &pv) { return (const dig_t *)(P.Llimbs + pv.off); }
 
-SLIP_DEV const dig_t *slip_rho(const SlipDev *S, int p) { return (const dig_t *)(S->Llimbs + S->rho_off[p]); }
+SLIP_DEV SlipPiv slip_piv_none(void)
+{
+    SlipPiv p; p.off = 0; p.len = 0; p.bits = 0; p.lo = 1; p.ctz = 0; p.invlen = 0; p.inv64 = 1; p.pad = 0;
+    return p;
+}
 
-/* make the cached inverse of pivot p's odd part valid modulo B^want.
- * b0,b1,b2: this wave's scratch.  Returns 0, or 1 if want exceeds the cache row. */
-SLIP_DEV int slip_ensure_inv(SlipDev *S, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2)
+/* ------------------------------------------------------------------ */
+/* in-lane arithmetic for one-limb operands (results up to 127 bits)   */
+/* ------------------------------------------------------------------ */
+SLIP_DEV int slip_bits128(slip_u128 v)
+{
+    uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t) v;
+    return hi ? 128 - slip_clz64(hi) : (lo ? 64 - slip_clz64(lo) : 0);
+}
+SLIP_DEV uint64_t slip_inv64(uint64_t d)            /* d odd */
+{
+    uint64_t x = d;
+    x *= 2 - d * x; x *= 2 - d * x; x *= 2 - d * x; x *= 2 - d * x; x *= 2 - d * x;
+    return x;
+}
+/* v / d exactly, v < 2^128, d a one-limb divisor with ctz z and 64-bit inverse of its odd part */
+SLIP_DEV slip_u128 slip_divexact128(slip_u128 v, uint64_t d, int z, uint64_t inv64)
+{
+    const uint64_t dodd = d >> z;
+    slip_u128 inv = (slip_u128) inv64;
+    inv = inv * ((slip_u128) 2 - (slip_u128) dodd * inv);          /* 128-bit inverse by one Newton step */
+    return (v >> z) * inv;
+}
+/* the 64-bit magnitude of a value of at most 2 digits, read as one aligned limb */
+SLIP_DEV uint64_t slip_limb0(const dig_t *p) { return *(const uint64_t *) p; }
+
+/* store a value of at most 4 digits (magnitude mag, sign sgn) as row i */
+SLIP_DEV void slip_store_small(const SlipParams &P, int i, slip_u128 mag, int sgn, int h)
+{
+    const int bits = slip_bits128(mag), len = (bits + 31) >> 5;
+    uint64_t *X = (uint64_t *)(P.xd + (int64_t) i * P.xcap);
+    X[0] = (uint64_t) mag;
+    if (len > 2) X[1] = (uint64_t)(mag >> 64);
+    SlipRow r; r.len = sgn < 0 ? -len : len; r.h = h; r.bits = bits; r.pad = 0;
+    P.xrow[i] = r;
+}
+
+/* ------------------------------------------------------------------ */
+/* wave-level pieces                                                    */
+/* ------------------------------------------------------------------ */
+/* make the cached inverse of pivot p's odd part valid modulo B^want (b0,b1,b2: wave scratch) */
+SLIP_DEV int slip_ensure_inv(const SlipParams &P, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2)
 {
     /* another wave may publish a longer inverse at any time: one lane reads, all agree */
-    int have = (int) slip_shfl_u32((uint32_t) *(volatile int32_t *) &S->invlen[p], 0);
+    int have = (int) slip_shfl_u32((uint32_t) *(volatile int32_t *) &P.piv[p].invlen, 0);
     if (have >= want) return 0;
-    if (want > S->invcap || want > S->wcap) return 1;
+    if (want > P.invcap || want > P.wcap) return 1;
     int target = 2 * have > want ? 2 * have : want;
-    if (target > S->invcap) target = S->invcap;
-    if (target > S->wcap) target = S->wcap;
-    const int ld = slip_abs(S->rho_len[p]);
-    const int z = S->rho_ctz[p];
+    if (target > P.invcap) target = P.invcap;
+    if (target > P.wcap) target = P.wcap;
+    const SlipPiv pv = P.piv[p];
+    const int ld = slip_abs(pv.len), z = pv.ctz;
     int lodd = ld - (z >> 5);
     if (lodd > target) lodd = target;
-    wb_copy_shr(b0, slip_rho(S, p), ld, z, lodd);
-    dig_t *inv = S->invd + (int64_t) p * S->invcap;
+    wb_copy_shr(b0, slip_piv_digits(P, pv), ld, z, lodd);
+    dig_t *inv = P.invd + (int64_t) p * P.invcap;
     wb_inv_extend(inv, have, target, b0, lodd, b1, b2);
     slip_fence_block();
-    if (slip_lane() == 0) slip_atomic_max_i32(&S->invlen[p], target);
+    if (slip_lane() == 0) slip_atomic_max_i32(&P.piv[p].invlen, target);
     slip_wave_sync();
     return 0;
 }
 
-/* store a W-digit result (normalising) as row i of x; returns 1 if it does not fit */
-SLIP_DEV int slip_store_x(SlipDev *S, int i, const dig_t *q, int W, int sign)
+/* store a W-digit result (normalising, zero padded to whole limbs) as row i; 1 if it does not fit */
+SLIP_DEV int slip_store_x(const SlipParams &P, int i, const dig_t *q, int W, int sign, int h)
 {
     const int lane = slip_lane();
-    int len = wb_len(q, W);
-    if (len > S->xcap) return 1;
-    dig_t *X = S->xd + (int64_t) i * S->xcap;
-    for (int c = lane; c < len; c += SLIP_WAVE) X[c] = q[c];
-    if (lane == 0) S->xlen[i] = sign < 0 ? -len : len;
+    const int len = wb_len(q, W);
+    if (len > P.xcap) return 1;
+    dig_t *X = P.xd + (int64_t) i * P.xcap;
+    const int lw = (len + 1) & ~1;
+    for (int c = lane; c < lw; c += SLIP_WAVE) X[c] = c < len ? q[c] : 0u;
+    if (lane == 0) {
+        SlipRow r; r.len = sign < 0 ? -len : len; r.h = h; r.pad = 0;
+        r.bits = len ? 32 * len - slip_clz32(q[len - 1]) : 0;
+        P.xrow[i] = r;
+    }
     slip_wave_sync();
     return 0;
 }
 
-/* History update of row r (slip_REF_triangular_solve.c:139-149, 248-257):
- *     x[r] <- x[r] * rho[pm] / rho[pd]      (pd < 0: no division)           */
-SLIP_DEV int slip_history(SlipDev *S, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2)
+/* History update of row r (slip_REF_triangular_solve.c:139-149, 248-257), one wavefront:
+ *     x[r] <- x[r] * rho[pm] / rho[pd]      (pd < 0: no division); the history tag is kept */
+SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2)
 {
-    const int32_t xl = S->xlen[r];
-    const int lx = slip_abs(xl);
-    dig_t *X = S->xd + (int64_t) r * S->xcap;
-    const int lm = slip_abs(S->rho_len[pm]);
-    int sign = slip_sgn(xl) * slip_sgn(S->rho_len[pm]);
-    int bq = wb_bits(X, lx) + S->rho_bits[pm];
+    const SlipRow xr = P.xrow[r];
+    const int lx = slip_abs(xr.len);
+    const dig_t *X = P.xd + (int64_t) r * P.xcap;
+    const SlipPiv m = P.piv[pm];
+    const int lm = slip_abs(m.len);
+    int sign = slip_sgn(xr.len) * slip_sgn(m.len);
+    int bq = xr.bits + m.bits;
     if (pd < 0) {
-        int W = (bq + 31) >> 5;
-        if (W > S->wcap) return 1;
-        wb_mul_lo(b0, X, lx, slip_rho(S, pm), lm, W);
-        return slip_store_x(S, r, b0, W, sign);
+        const int W = (bq + 31) >> 5;
+        if (W > P.wcap) return 1;
+        wb_mul_lo(b0, X, lx, slip_piv_digits(P, m), lm, W);
+        return slip_store_x(P, r, b0, W, sign, xr.h);
     }
-    bq -= S->rho_bits[pd] - 1;
-    const int W = (bq + 31) >> 5, zh = S->rho_ctz[pd], W2 = W + ((zh + 31) >> 5);
-    if (W2 > S->wcap) return 1;
-    if (slip_ensure_inv(S, pd, W, b0, b1, b2)) return 1;
-    wb_mul_lo(b0, X, lx, slip_rho(S, pm), lm, W2);
+    const SlipPiv d = P.piv[pd];
+    bq -= d.bits - 1;
+    const int W = (bq + 31) >> 5, zh = d.ctz, W2 = W + ((zh + 31) >> 5);
+    if (W2 > P.wcap) return 1;
+    if (slip_ensure_inv(P, pd, W, b0, b1, b2)) return 1;
+    wb_mul_lo(b0, X, lx, slip_piv_digits(P, m), lm, W2);
     wb_copy_shr(b1, b0, W2, zh, W);
-    wb_mul_lo(b2, b1, W, S->invd + (int64_t) pd * S->invcap, W, W);
-    return slip_store_x(S, r, b2, W, sign * slip_sgn(S->rho_len[pd]));
+    wb_mul_lo(b2, b1, W, P.invd + (int64_t) pd * P.invcap, W, W);
+    return slip_store_x(P, r, b2, W, sign * slip_sgn(d.len), xr.h);
 }
 
-/* One IPGE update (slip_REF_triangular_solve.c:156-241) of target row i by
- * source row j (pivot position jn) through the L entry m:
- *     x[i] <- ( hist(x[i]) * rho[jn] - L_m * x[j] ) / rho[jn-1]
- * hist() being the history update to level jn-1 when h[i] < jn-1.
- * One wavefront; everything modulo B^W (see wave_bigint.h).  Returns 1 when a
- * buffer is too small. */
-SLIP_DEV int slip_ipge(SlipDev *S, int i, int j, int jn, int64_t m, dig_t *b0, dig_t *b1, dig_t *b2)
+/* One IPGE update (slip_REF_triangular_solve.c:156-241) of target row i by source row j
+ * (pivot position jn) through the L entry m, one wavefront, everything modulo B^W:
+ *     x[i] <- ( hist(x[i]) * rho[jn] - L_m * x[j] ) / rho[jn-1]                          */
+SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m, dig_t *b0, dig_t *b1, dig_t *b2)
 {
-    const int32_t xl = S->xlen[i];
-    const int lx = slip_abs(xl), sx = slip_sgn(xl);
-    dig_t *X = S->xd + (int64_t) i * S->xcap;
-    const int32_t rl = S->rho_len[jn];
-    const int lr = slip_abs(rl), sr = slip_sgn(rl), br = S->rho_bits[jn];
-    const int32_t ml = S->Llen[m];
-    const int ll = slip_abs(ml), sl = slip_sgn(ml);
-    const dig_t *Lm = (const dig_t *)(S->Llimbs + S->Loff[m]);
-    const int32_t jl = S->xlen[j];
-    const int lj = slip_abs(jl), sj = slip_sgn(jl);
-    const dig_t *Xj = S->xd + (int64_t) j * S->xcap;
-    const int hi = S->h[i];
+    const SlipRow xi = P.xrow[i], xj = P.xrow[j];
+    const SlipEnt le = P.Le[m];
+    const SlipPiv R = P.piv[jn];
+    const int lx = slip_abs(xi.len), sx = slip_sgn(xi.len);
+    const dig_t *X = P.xd + (int64_t) i * P.xcap;
+    const int lr = slip_abs(R.len), sr = slip_sgn(R.len), br = R.bits;
+    const int ll = slip_abs(le.len), sl = slip_sgn(le.len);
+    const dig_t *Lm = (const dig_t *)(P.Llimbs + le.off);
+    const int lj = slip_abs(xj.len), sj = slip_sgn(xj.len);
+    const dig_t *Xj = P.xd + (int64_t) j * P.xcap;
+    const int hi = xi.h;
     const int has_d = jn >= 1;
-    int ld = 0, sd = 1, bd = 0, zd = 0;
-    if (has_d) { const int32_t dl = S->rho_len[jn - 1]; ld = slip_abs(dl); sd = slip_sgn(dl); bd = S->rho_bits[jn - 1]; zd = S->rho_ctz[jn - 1]; }
+    SlipPiv D = slip_piv_none();
+    if (has_d) D = P.piv[jn - 1];
+    const int ld = slip_abs(D.len), sd = has_d ? slip_sgn(D.len) : 1, bd = D.bits, zd = D.ctz;
     const int hist = lx != 0 && has_d && hi < jn - 1;
     const int hdiv = hist && hi > -1;
     int bh = 0, zh = 0, sh = 1;
-    if (hdiv) { bh = S->rho_bits[hi]; zh = S->rho_ctz[hi]; sh = slip_sgn(S->rho_len[hi]); }
+    if (hdiv) { const SlipPiv H = P.piv[hi]; bh = H.bits; zh = H.ctz; sh = slip_sgn(H.len); }
 
     /* bit bounds -> working widths */
-    const int bx = wb_bits(X, lx);
-    const int bxp = !lx ? 0 : (!hist ? bx : (hdiv ? bx + bd - bh + 1 : bx + bd));
-    const int b1b = lx ? bxp + br : 0, b2b = wb_bits(Lm, ll) + wb_bits(Xj, lj);
+    const int bxp = !lx ? 0 : (!hist ? xi.bits : (hdiv ? xi.bits + bd - bh + 1 : xi.bits + bd));
+    const int b1b = lx ? bxp + br : 0, b2b = le.bits + xj.bits;
     const int bnum = (b1b > b2b ? b1b : b2b) + 1;
     const int bq = has_d ? bnum - bd + 1 : bnum;
     const int W = (bq + 1 + 31) >> 5;                       /* + sign bit */
     const int W1 = W + (has_d ? ((zd + 31) >> 5) : 0);
     const int W2 = W1 + (hdiv ? ((zh + 31) >> 5) : 0);
-    if (W2 > S->wcap) return 1;
-    if (hdiv && slip_ensure_inv(S, hi, W1, b0, b1, b2)) return 1;
-    if (has_d && slip_ensure_inv(S, jn - 1, W, b0, b1, b2)) return 1;
+    if (W2 > P.wcap) return 1;
+    if (hdiv && slip_ensure_inv(P, hi, W1, b0, b1, b2)) return 1;
+    if (has_d && slip_ensure_inv(P, jn - 1, W, b0, b1, b2)) return 1;
 
     /* P1 = hist(x_i) * rho_jn  -> b1, sign s1 */
     int s1 = sx * sr;
     if (lx == 0) {
-        /* nothing: handled below */
+        /* handled below */
     } else if (!hist) {
-        wb_mul_lo(b1, X, lx, slip_rho(S, jn), lr, W1);
+        wb_mul_lo(b1, X, lx, slip_piv_digits(P, R), lr, W1);
     } else if (!hdiv) {
-        wb_mul_lo(b0, X, lx, slip_rho(S, jn - 1), ld, W1);
-        wb_mul_lo(b1, b0, W1, slip_rho(S, jn), lr, W1);
+        wb_mul_lo(b0, X, lx, slip_piv_digits(P, D), ld, W1);
+        wb_mul_lo(b1, b0, W1, slip_piv_digits(P, R), lr, W1);
         s1 *= sd;
     } else {
-        wb_mul_lo(b0, X, lx, slip_rho(S, jn - 1), ld, W2);
+        wb_mul_lo(b0, X, lx, slip_piv_digits(P, D), ld, W2);
         wb_copy_shr(b1, b0, W2, zh, W1);
-        wb_mul_lo(b0, b1, W1, S->invd + (int64_t) hi * S->invcap, W1, W1);
-        wb_mul_lo(b1, b0, W1, slip_rho(S, jn), lr, W1);
+        wb_mul_lo(b0, b1, W1, P.invd + (int64_t) hi * P.invcap, W1, W1);
+        wb_mul_lo(b1, b0, W1, slip_piv_digits(P, R), lr, W1);
         s1 *= sd * sh;
     }
     /* P2 = L_m * x_j -> b2, sign s2 */
@@ -269,7 +350,7 @@ SLIP_DEV int slip_ipge(SlipDev *S, int i, int j, int jn, int64_t m, dig_t *b0, d
     dig_t *Q = b1;
     if (has_d) {
         wb_copy_shr(b0, b1, W1, zd, W);
-        wb_mul_lo(b2, b0, W, S->invd + (int64_t)(jn - 1) * S->invcap, W, W);
+        wb_mul_lo(b2, b0, W, P.invd + (int64_t)(jn - 1) * P.invcap, W, W);
         Q = b2; sT *= sd;
     }
     /* two's complement -> sign-magnitude */
@@ -277,9 +358,7 @@ SLIP_DEV int slip_ipge(SlipDev *S, int i, int j, int jn, int64_t m, dig_t *b0, d
         wb_addsub(Q, (const dig_t *) 0, 0, Q, W, W, 1, 0u);
         sT = -sT;
     }
-    int rc = slip_store_x(S, i, Q, W, sT);
-    if (slip_lane() == 0) S->h[i] = jn;
-    return rc;
+    return slip_store_x(P, i, Q, W, sT, jn);
 }
 
 /* is |a| * 2^sa >= |b| * 2^sb ?  a, b normalised; scratch b0, b1 of wcap digits */
@@ -295,43 +374,77 @@ SLIP_DEV int slip_ge_shifted(const dig_t *a, int la, int sa, const dig_t *b, int
     return wb_cmp(b0, W, b1, W) >= 0;
 }
 
+/* in-lane history update  x * rho[pm] / rho[pd]  when everything is one limb; 0 if not applicable */
+SLIP_DEV int slip_history_small(const SlipParams &P, const SlipRow &xr, uint64_t xv, int pm, int pd,
+                                slip_u128 *out, int *osgn)
+{
+    const SlipPiv m = P.piv[pm];
+    if (slip_abs(xr.len) > 2 || slip_abs(m.len) > 2) return 0;
+    slip_u128 y = (slip_u128) xv * m.lo;
+    int s = slip_sgn(xr.len) * slip_sgn(m.len);
+    if (pd >= 0) {
+        const SlipPiv d = P.piv[pd];
+        if (slip_abs(d.len) > 2) return 0;
+        y = slip_divexact128(y, d.lo, d.ctz, d.inv64);
+        s *= slip_sgn(d.len);
+    }
+    *out = y; *osgn = s;
+    return 1;
+}
+
+/* left-aligned leading 64 bits of a normalised l-digit magnitude */
+SLIP_DEV uint64_t slip_top64(const dig_t *X, int l)
+{
+    uint64_t top = ((uint64_t) X[l - 1] << 32) | (l >= 2 ? X[l - 2] : 0u);
+    const int sh = slip_clz32(X[l - 1]);
+    if (sh) top = (top << sh) | (l >= 3 ? (uint64_t)(X[l - 3] >> (32 - sh)) : 0ull);
+    return top;
+}
+
 /* ------------------------------------------------------------------ */
 /* one column; returns a SLIPDEV_* status (0 = committed)              */
 /* ------------------------------------------------------------------ */
-SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
+template <bool BM_LDS, bool SCR_LDS>
+SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uint32_t *lds,
                             unsigned long long *t_read, unsigned long long *t_upd,
                             unsigned long long *t_src, unsigned long long *t_str)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
-    const int n = S->n, col = S->q[k];
+    const int col = P.q[k];
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    volatile int64_t *sv64 = (volatile int64_t *)(lds + SLIP_LDS_VARS);
     uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
-    uint32_t *bm = S->bitmap_in_lds ? lds + SLIP_LDS_BITMAP : S->gbitmap;
-    const int wcap = S->wcap;
-    dig_t *b0 = S->scratch_in_lds ? lds + SLIP_LDS_BITMAP + (S->bitmap_in_lds ? S->bm_words : 0) + (int64_t) wave * 3 * wcap
-                                  : S->gscratch + (int64_t) wave * 3 * wcap;
+    uint32_t *work = lds + SLIP_LDS_WORK;
+    uint32_t *bm = BM_LDS ? lds + SLIP_LDS_BITMAP : P.gbitmap;
+    const int wcap = P.wcap;
+    dig_t *b0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
+                        : P.gscratch + (int64_t) wave * 3 * wcap;
     dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
     unsigned long long c_read = 0, c_upd = 0, c_src = 0, c_str = 0;
-
     SLIP_STAMP_INIT();
+
     /* ---- phase 0: clear the pattern bitmap ---- */
-    for (int w = tid; w < S->bm_words; w += T) bm[w] = 0;
-    if (tid == 0) { sv[SV_ERR] = 0; }
+    for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
+    if (tid == 0) { sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; }
     slip_block_sync();
 
     /* ---- phase 1: scatter A(:,col) into x (slip_REF_triangular_solve.c:105-119) ---- */
-    for (int64_t p = S->Ap[col] + tid; p < S->Ap[col + 1]; p += T) {
-        const int row = S->Ai[p];
-        const int pos = S->pinv[row];
+    for (int64_t p = P.Ap[col] + tid; p < P.Ap[col + 1]; p += T) {
+        const int row = P.Ai[p];
+        const int pos = P.pinv[row];
         slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
-        const int32_t al = S->Alen[p];
+        const int32_t al = P.Alen[p];
         const int la = slip_abs(al);
-        const dig_t *src = (const dig_t *)(S->Alimbs + S->Aoff[p]);
-        dig_t *X = S->xd + (int64_t) row * S->xcap;
-        if (la > S->xcap) sv[SV_ERR] = 1;
-        else for (int c = 0; c < la; c++) X[c] = src[c];
-        S->xlen[row] = al;
-        S->h[row] = -1;
+        const dig_t *src = (const dig_t *)(P.Alimbs + P.Aoff[p]);
+        dig_t *X = P.xd + (int64_t) row * P.xcap;
+        SlipRow r; r.len = al; r.h = -1; r.pad = 0; r.bits = 0;
+        if (la > P.xcap) sv[SV_ERR] = 1;
+        else {
+            const int lw = (la + 1) & ~1;
+            for (int c = 0; c < lw; c++) X[c] = c < la ? src[c] : 0u;
+            r.bits = la ? 32 * la - slip_clz32(src[la - 1]) : 0;
+        }
+        P.xrow[row] = r;
         c_read += 4 + 8 * (unsigned long long)((la + 1) >> 1);
     }
     slip_block_sync();
@@ -339,44 +452,135 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
     SLIP_STAMP(0);
 
     /* ---- phase 2: ascending sweep over the pivotal part of the pattern ---- */
-    int cur = -1;
-    for (;;) {
-        slip_block_sync();
-        const int jn = slip_bitmap_next(bm, cur + 1, k);
-        if (jn < 0) break;
-        cur = jn;
-        const int j = S->row_perm[jn];
-        if (wave == 0) {
-            /* bring x[j] to its final value: history update to level jn-1 */
-            if (S->xlen[j] != 0 && S->h[j] < jn - 1)
-                if (slip_history(S, j, jn - 1, S->h[j], b0, b1, b2)) sv[SV_ERR] = 1;
-        }
-        slip_block_sync();
-        const int32_t xjl = S->xlen[j];
-        const int64_t m0 = S->Lp[jn], m1 = S->Lp[jn + 1];
-        if (xjl != 0 && tid == 0) {
-            c_src++;
-            c_read += 8ull * ((slip_abs(S->rho_len[jn]) + 1) >> 1)
-                    + (jn >= 1 ? 8ull * ((slip_abs(S->rho_len[jn - 1]) + 1) >> 1) : 0ull);
-        }
-        for (int64_t m = m0 + wave; m < m1; m += nw) {
-            const int i = S->Li[m];
-            const int inew = S->pinv[i];
-            const int32_t ml = S->Llen[m];
-            /* structural discovery (what the reference's DFS does) */
-            int fresh = 0;
-            if (lane == 0) {
-                uint32_t bit = 1u << (inew & 31);
-                uint32_t old = slip_atomic_or_u32(&bm[inew >> 5], bit);
-                fresh = !(old & bit);
-                if (fresh) { S->xlen[i] = 0; S->h[i] = -1; }
-                if (xjl != 0) { c_str++; c_read += 4 + 8ull * ((slip_abs(ml) + 1) >> 1); }
+    {
+        int cur = -1, step = 0;
+        int pj = -1, pjn = -1;                       /* the source whose queued (wave) updates are pending */
+        int dj = -1, dys = 1, dh = -1;               /* finalised one-limb source value not yet written back */
+        slip_u128 dy = 0;
+        for (;; step++) {
+            slip_block_sync();
+            /* write back the previous source's finalised value: every thread has read the old one by now */
+            if (dj >= 0) { if (tid == 0) slip_store_small(P, dj, dy, dys, dh); dj = -1; }
+            /* queued multi-limb updates of the previous source: one wavefront each */
+            const int nq = sv[SV_CNT0 + (step + 2) % 3];
+            if (tid == 0) sv[SV_CNT0 + (step + 1) % 3] = 0;
+            if (nq > 0) {
+                slip_block_sync();
+                const uint32_t *wlp = work + ((step + 1) & 1) * 2 * SLIP_WORK_CAP;
+                const int64_t pm0 = P.Lp[pjn];
+                for (int t = wave; t < nq; t += nw) {
+                    const int64_t m = pm0 + (int64_t) wlp[2 * t];
+                    const int i = (int) wlp[2 * t + 1];
+                    if (slip_ipge_wave(P, i, pj, pjn, m, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
+                }
+                slip_block_sync();
             }
-            slip_wave_sync();
-            if (xjl != 0 && inew > jn && ml != 0) {
-                if (lane == 0) c_upd++;
-                if (slip_ipge(S, i, j, jn, m, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
+            const int jn = slip_bitmap_next(bm, cur + 1, k);
+            if (jn < 0) break;
+            cur = jn;
+            const int j = P.row_perm[jn];
+            SlipRow xj = P.xrow[j];
+            uint64_t xjv = xj.len != 0 ? slip_limb0(P.xd + (int64_t) j * P.xcap) : 0;
+            /* bring x[j] to its final value: history update to level jn-1 (:139-149) */
+            if (xj.len != 0 && xj.h < jn - 1) {
+                slip_u128 y = 0; int ys = 1;
+                if (slip_history_small(P, xj, xjv, jn - 1, xj.h, &y, &ys)) {
+                    /* every thread derives the same value in registers; thread 0 stores it one step later */
+                    dj = j; dy = y; dys = ys; dh = xj.h;
+                    const int yb = slip_bits128(y), yl = (yb + 31) >> 5;
+                    xj.len = ys < 0 ? -yl : yl; xj.bits = yb; xjv = (uint64_t) y;
+                } else {
+                    slip_block_sync();
+                    if (wave == 0) {
+                        if (slip_history_wave(P, j, jn - 1, xj.h, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
+                    }
+                    slip_block_sync();
+                    xj = P.xrow[j];
+                    xjv = slip_limb0(P.xd + (int64_t) j * P.xcap);
+                }
             }
+            const int src_nz = xj.len != 0;
+            const int64_t m0 = P.Lp[jn], m1 = P.Lp[jn + 1];
+            const SlipPiv R = P.piv[jn];
+            SlipPiv D = slip_piv_none();
+            if (jn >= 1) D = P.piv[jn - 1];
+            const int src_small = slip_abs(xj.len) <= 2 && slip_abs(R.len) <= 2 && slip_abs(D.len) <= 2;
+            if (src_nz && tid == 0) {
+                c_src++;
+                c_read += 8ull * slip_limbs(R.len) + (jn >= 1 ? 8ull * slip_limbs(D.len) : 0ull);
+            }
+            uint32_t *wl = work + (step & 1) * 2 * SLIP_WORK_CAP;
+            volatile int32_t *wcnt = &sv[SV_CNT0 + step % 3];
+            /* stream L(:,jn): one entry per lane, SLIP_WORK_CAP entries per pass */
+            for (int64_t mb = m0; mb < m1; mb += SLIP_WORK_CAP) {
+                if (mb > m0) {
+                    /* long column: drain the queue of the previous pass before refilling it */
+                    slip_block_sync();
+                    if (dj >= 0) {                      /* the wave path reads x[j] from memory */
+                        if (tid == 0) slip_store_small(P, dj, dy, dys, dh);
+                        dj = -1;
+                        slip_block_sync();
+                    }
+                    const int nq2 = *wcnt;
+                    for (int t = wave; t < nq2; t += nw) {
+                        const int64_t m = m0 + (int64_t) wl[2 * t];
+                        if (slip_ipge_wave(P, (int) wl[2 * t + 1], j, jn, m, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
+                    }
+                    slip_block_sync();
+                    if (tid == 0) *wcnt = 0;
+                    slip_block_sync();
+                }
+                const int64_t me = mb + SLIP_WORK_CAP < m1 ? mb + SLIP_WORK_CAP : m1;
+                for (int64_t m = mb + tid; m < me; m += T) {
+                    const int i = P.Li[m];
+                    const SlipEnt le = P.Le[m];
+                    const int inew = P.pinv[i];
+                    /* structural discovery (what the reference's DFS does) */
+                    const uint32_t bit = 1u << (inew & 31);
+                    const uint32_t old = slip_atomic_or_u32(&bm[inew >> 5], bit);
+                    SlipRow xi;
+                    if (!(old & bit)) { xi.len = 0; xi.h = -1; xi.bits = 0; xi.pad = 0; P.xrow[i] = xi; }
+                    else xi = P.xrow[i];
+                    if (!src_nz) continue;
+                    c_str++; c_read += 4 + 8ull * slip_limbs(le.len);
+                    if (inew <= jn || le.len == 0) continue;
+                    c_upd++;
+                    /* ---- one-limb operands: finish the update in this lane ---- */
+                    int done = 0;
+                    if (src_small && slip_abs(le.len) <= 2 && slip_abs(xi.len) <= 2) {
+                        const int lx = xi.len != 0, has_d = jn >= 1;
+                        const int hist = lx && has_d && xi.h < jn - 1, hdiv = hist && xi.h > -1;
+                        SlipPiv H = slip_piv_none();
+                        if (hdiv) H = P.piv[xi.h];
+                        const int bxp = !lx ? 0 : (!hist ? xi.bits : (hdiv ? xi.bits + D.bits - H.bits + 1 : xi.bits + D.bits));
+                        const int b1b = lx ? bxp + R.bits : 0, b2b = le.bits + xj.bits;
+                        const int bnum = (b1b > b2b ? b1b : b2b) + 1;
+                        if (bnum <= 126 && (!hdiv || slip_abs(H.len) <= 2)) {
+                            slip_u128 y = 0; int s1 = slip_sgn(xi.len) * slip_sgn(R.len);
+                            if (lx) {
+                                y = (slip_u128) slip_limb0(P.xd + (int64_t) i * P.xcap);
+                                if (hist) { y *= D.lo; s1 *= slip_sgn(D.len); }
+                                if (hdiv) { y = slip_divexact128(y, H.lo, H.ctz, H.inv64); s1 *= slip_sgn(H.len); }
+                                y *= R.lo;
+                            }
+                            const slip_u128 p2 = (slip_u128) slip_limb0((const dig_t *)(P.Llimbs + le.off)) * xjv;
+                            const int s2 = slip_sgn(le.len) * slip_sgn(xj.len);
+                            slip_u128 mag; int sT;
+                            if (!lx) { mag = p2; sT = -s2; }
+                            else if (s1 == s2) { if (y >= p2) { mag = y - p2; sT = s1; } else { mag = p2 - y; sT = -s1; } }
+                            else { mag = y + p2; sT = s1; }
+                            if (has_d) { mag = slip_divexact128(mag, D.lo, D.ctz, D.inv64); sT *= slip_sgn(D.len); }
+                            slip_store_small(P, i, mag, sT, jn);
+                            done = 1;
+                        }
+                    }
+                    if (!done) {
+                        const int at = slip_atomic_add_i32((int32_t *) wcnt, 1);
+                        wl[2 * at] = (uint32_t)(m - m0); wl[2 * at + 1] = (uint32_t) i;
+                    }
+                }
+            }
+            pj = j; pjn = jn;
         }
     }
     slip_block_sync();
@@ -384,113 +588,209 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
     SLIP_STAMP(1);
 
     /* ---- phase 3: read the bitmap in order = the sorted pattern (slip_sort_xi.c) ---- */
-    const int nwords = S->bm_words;
+    const int nwords = P.bm_words;
     const int per = (nwords + T - 1) / T;
-    int w0 = tid * per, w1 = w0 + per; if (w1 > nwords) w1 = nwords;
-    uint64_t cnt = 0;
+    int w0 = tid * per, w1 = w0 + per;
+    if (w0 > nwords) w0 = nwords;
+    if (w1 > nwords) w1 = nwords;
+    uint64_t cntA = 0, cntU = 0;
     for (int w = w0; w < w1; w++) {
-        uint32_t word = bm[w];
+        const uint32_t word = bm[w];
         uint32_t below;
         if ((w + 1) * 32 <= k) below = word;
         else if (w * 32 >= k) below = 0;
         else below = word & ((1u << (k - w * 32)) - 1u);
-        cnt += ((uint64_t) slip_popc32(word) << 32) | (uint64_t) slip_popc32(below);
+        cntA += (uint64_t) slip_popc32(word); cntU += (uint64_t) slip_popc32(below);
     }
-    uint64_t tot;
-    uint64_t ex = slip_block_scan(cnt, scan_tmp, &tot);
+    uint64_t exA, exU, totA, totU_;
+    slip_block_scan2(cntA, cntU, scan_tmp, &exA, &exU, &totA, &totU_);
     {
-        int o = (int)(ex >> 32);
+        int o = (int) exA;
         for (int w = w0; w < w1; w++) {
             uint32_t word = bm[w];
-            while (word) { int b = slip_ctz32(word); word &= word - 1; S->pat[o++] = w * 32 + b; }
+            while (word) { int b = slip_ctz32(word); word &= word - 1; P.pat[o++] = w * 32 + b; }
         }
     }
-    const int npat = (int)(tot >> 32), nU = (int)(tot & 0xFFFFFFFFu), nL = npat - nU;
+    const int npat = (int) totA, nU = (int) totU_, nL = npat - nU;
     slip_block_sync();
     SLIP_STAMP(2);
 
     /* ---- phase 4: history update of the non-pivotal rows to level k-1 (:248-257) ---- */
     if (k >= 1) {
-        for (int t = wave; t < nL; t += nw) {
-            const int r = S->row_perm[S->pat[nU + t]];
-            if (S->xlen[r] != 0 && S->h[r] < k - 1)
-                if (slip_history(S, r, k - 1, S->h[r], b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
+        volatile int32_t *wcnt = &sv[SV_CNT0];
+        if (tid == 0) *wcnt = 0;
+        /* rho[k-1] is the multiplier of every row: stage its digits once (LDS when it fits) */
+        const SlipPiv M = P.piv[k - 1];
+        const int lm = slip_abs(M.len);
+        const dig_t *Mg = slip_piv_digits(P, M);
+        dig_t *Ms = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + nw * 3 * wcap : (dig_t *) 0;
+        const dig_t *Md = Mg;
+        if (SCR_LDS && lm <= wcap) { for (int c = tid; c < lm; c += T) Ms[c] = Mg[c]; Md = Ms; }
+        slip_block_sync();
+        SLIP_STAMP(8);
+        uint32_t *wl = work;
+        for (int t0 = 0; t0 < nL; t0 += SLIP_WORK_CAP) {
+            const int te = t0 + SLIP_WORK_CAP < nL ? t0 + SLIP_WORK_CAP : nL;
+            for (int t = t0 + tid; t < te; t += T) {
+                const int r = P.row_perm[P.pat[nU + t]];
+                const SlipRow xr = P.xrow[r];
+                if (xr.len == 0 || xr.h >= k - 1) continue;
+                int done = 0;
+                if (slip_abs(xr.len) <= 2) {
+                    const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                    slip_u128 y = 0; int ys = 1;
+                    if (slip_history_small(P, xr, xv, k - 1, xr.h, &y, &ys)) {
+                        slip_store_small(P, r, y, ys, xr.h);
+                        done = 1;
+                    } else if (xr.h < 0 && lm + 2 <= P.xcap) {
+                        /* one limb times a long pivot, no division: this lane walks the pivot's digits */
+                        dig_t *X = P.xd + (int64_t) r * P.xcap;
+                        const uint64_t a0 = xv & 0xFFFFFFFFu, a1 = xv >> 32;
+                        uint64_t carry = 0;              /* < 2^64 */
+                        for (int c = 0; c < lm; c++) {
+                            const uint64_t d = Md[c];
+                            const uint64_t lo = a0 * d + (carry & 0xFFFFFFFFu);          /* < 2^64 */
+                            X[c] = (uint32_t) lo;
+                            carry = a1 * d + (carry >> 32) + (lo >> 32);                 /* < 2^64 */
+                        }
+                        int len = lm;
+                        if (carry) { X[len++] = (uint32_t) carry; if (carry >> 32) X[len++] = (uint32_t)(carry >> 32); }
+                        if (len & 1) X[len] = 0;
+                        SlipRow nr; nr.len = (slip_sgn(xr.len) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = xr.h; nr.pad = 0;
+                        nr.bits = 32 * len - slip_clz32(X[len - 1]);
+                        P.xrow[r] = nr;
+                        done = 1;
+                    }
+                }
+                if (!done) { const int at = slip_atomic_add_i32((int32_t *) wcnt, 1); wl[at] = (uint32_t) r; }
+            }
+            slip_block_sync();
+            SLIP_STAMP(9);
+            const int nq = *wcnt;
+#ifdef SLIP_PROFILING
+            if (tid == 0) st->prof[11] += (unsigned long long) nq;
+#endif
+            for (int t = wave; t < nq; t += nw) {
+                const int r = (int) wl[t];
+                const int hr = P.xrow[r].h;
+                if (slip_history_wave(P, r, k - 1, hr, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
+            }
+            slip_block_sync();
+            SLIP_STAMP(10);
+            if (tid == 0) *wcnt = 0;
+            slip_block_sync();
         }
     }
-    slip_block_sync();
     if (sv[SV_ERR]) return SLIPDEV_GROW_X;
     SLIP_STAMP(3);
 
     /* ---- phase 5: column-window cap, then the pivot search ---- */
     {
         int mx = 0;
-        for (int t = tid; t < npat; t += T) { int l = slip_abs(S->xlen[S->row_perm[S->pat[t]]]); if (l > mx) mx = l; }
-        uint64_t dummy;
-        /* max via a scan-free reduction: reuse scan_tmp through atomics on LDS var */
-        if (tid == 0) sv[SV_MAXDIG] = 0;
-        slip_block_sync();
+        for (int t = tid; t < npat; t += T) { int l = slip_abs(P.xrow[P.row_perm[P.pat[t]]].len); if (l > mx) mx = l; }
         if (mx > 0) slip_atomic_max_i32((int32_t *) &sv[SV_MAXDIG], mx);
         slip_block_sync();
-        (void) dummy;
     }
     const int maxdig = sv[SV_MAXDIG];
-    if (S->limb_cap > 0 && ((maxdig + 1) >> 1) > S->limb_cap) return SLIPDEV_WINDOW_END;
+    if (P.limb_cap > 0 && ((maxdig + 1) >> 1) > P.limb_cap) return SLIPDEV_WINDOW_END;
 
-    /* kind of search: 0 smallest, 1 largest, 2 first nonzero (slip_get_pivot.c:58-155) */
-    const int scheme = S->pivot_scheme;
+    /* kind of search: 0 smallest, 1 largest, 2 first nonzero (slip_get_pivot.c:58-155).
+     * Lanes order the candidates by (bit length, leading 64 bits); the candidates that tie on
+     * that key are compared exactly, ties resolved towards the earlier pattern position. */
+    const int scheme = P.pivot_scheme;
     const int kind = (scheme == 2) ? 2 : ((scheme == 4 || scheme == 5) ? 1 : 0);
-    int best = -1;                                   /* index t into the L part */
-    for (int t = wave; t < nL; t += nw) {
-        const int r = S->row_perm[S->pat[nU + t]];
-        const int lr_ = slip_abs(S->xlen[r]);
-        if (lr_ == 0) continue;
-        if (best < 0) { best = t; continue; }
-        if (kind == 2) continue;
-        const int rb = S->row_perm[S->pat[nU + best]];
-        const int c = wb_cmp(S->xd + (int64_t) rb * S->xcap, slip_abs(S->xlen[rb]), S->xd + (int64_t) r * S->xcap, lr_);
-        if ((kind == 0 && c > 0) || (kind == 1 && c < 0)) best = t;
+    int best = -1;
+    {
+        uint64_t k1 = ~0ull;                                     /* (key, t) packed: smaller is better */
+        for (int t = tid; t < nL; t += T) {
+            const SlipRow xr = P.xrow[P.row_perm[P.pat[nU + t]]];
+            if (xr.len == 0) continue;
+            const uint64_t key = kind == 2 ? 0 : (kind == 0 ? (uint64_t) xr.bits : (uint64_t)(0x7FFFFFFF - xr.bits));
+            const uint64_t c = (key << 32) | (uint32_t) t;
+            if (c < k1) k1 = c;
+        }
+        k1 = slip_block_min_u64(k1, scan_tmp);
+        if (k1 == ~0ull) return SLIPDEV_SINGULAR;
+        if (kind == 2) best = (int)(k1 & 0xFFFFFFFFu);
+        else {
+            const uint32_t bkey = (uint32_t)(k1 >> 32);
+            const int bbits = kind == 0 ? (int) bkey : 0x7FFFFFFF - (int) bkey;
+            uint64_t k2 = ~0ull;
+            for (int t = tid; t < nL; t += T) {
+                const int r = P.row_perm[P.pat[nU + t]];
+                const SlipRow xr = P.xrow[r];
+                if (xr.len == 0 || xr.bits != bbits) continue;
+                const uint64_t top = slip_top64(P.xd + (int64_t) r * P.xcap, slip_abs(xr.len));
+                const uint64_t key = kind == 0 ? top : ~top;
+                if (key < k2) k2 = key;
+            }
+            const uint64_t m2 = slip_block_min_u64(k2, scan_tmp);
+            if (tid == 0) sv[SV_LISTN] = 0;
+            slip_block_sync();
+            for (int t = tid; t < nL; t += T) {
+                const int r = P.row_perm[P.pat[nU + t]];
+                const SlipRow xr = P.xrow[r];
+                if (xr.len == 0 || xr.bits != bbits) continue;
+                const uint64_t top = slip_top64(P.xd + (int64_t) r * P.xcap, slip_abs(xr.len));
+                if ((kind == 0 ? top : ~top) != m2) continue;
+                const int at = slip_atomic_add_i32((int32_t *) &sv[SV_LISTN], 1);
+                if (at < 2 * SLIP_WORK_CAP) work[at] = (uint32_t) t;
+            }
+            slip_block_sync();
+            const int nc = sv[SV_LISTN];
+            /* every wave performs the same reduction (wave-uniform, reads only) */
+            if (nc <= 2 * SLIP_WORK_CAP) {
+                for (int c = 0; c < nc; c++) {
+                    const int t = (int) work[c];
+                    if (best < 0) { best = t; continue; }
+                    int cmp = 0;
+                    if (bbits > 64) {
+                        const int rb = P.row_perm[P.pat[nU + best]], r = P.row_perm[P.pat[nU + t]];
+                        cmp = wb_cmp(P.xd + (int64_t) rb * P.xcap, slip_abs(P.xrow[rb].len),
+                                     P.xd + (int64_t) r * P.xcap, slip_abs(P.xrow[r].len));
+                    }
+                    if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && t < best)) best = t;
+                }
+            } else {                                              /* too many ties for the list */
+                for (int t = 0; t < nL; t++) {
+                    const int r = P.row_perm[P.pat[nU + t]];
+                    const SlipRow xr = P.xrow[r];
+                    if (xr.len == 0 || xr.bits != bbits) continue;
+                    if (best < 0) { best = t; continue; }
+                    const int rb = P.row_perm[P.pat[nU + best]];
+                    const int cmp = wb_cmp(P.xd + (int64_t) rb * P.xcap, slip_abs(P.xrow[rb].len),
+                                           P.xd + (int64_t) r * P.xcap, slip_abs(xr.len));
+                    if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0)) best = t;
+                }
+            }
+            slip_block_sync();
+        }
     }
-    if (lane == 0) sv[SV_BEST + wave] = best;
-    slip_block_sync();
-    /* every wave reduces the per-wave candidates identically (ties -> smaller t) */
-    best = -1;
-    for (int w = 0; w < nw; w++) {
-        const int t = sv[SV_BEST + w];
-        if (t < 0) continue;
-        if (best < 0) { best = t; continue; }
-        if (kind == 2) { if (t < best) best = t; continue; }
-        const int rb = S->row_perm[S->pat[nU + best]], r = S->row_perm[S->pat[nU + t]];
-        const int c = wb_cmp(S->xd + (int64_t) rb * S->xcap, slip_abs(S->xlen[rb]), S->xd + (int64_t) r * S->xcap, slip_abs(S->xlen[r]));
-        if ((kind == 0 && c > 0) || (kind == 1 && c < 0) || (c == 0 && t < best)) best = t;
-    }
-    if (best < 0) return SLIPDEV_SINGULAR;
-    int pivrow = S->row_perm[S->pat[nU + best]];
+    int pivrow = P.row_perm[P.pat[nU + best]];
     /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146) */
     if (scheme == 1 || scheme == 3 || scheme == 4) {
-        const int pc = S->pinv[col];
-        const int diag_ok = pc >= k && ((bm[pc >> 5] >> (pc & 31)) & 1u) && S->xlen[col] != 0;
+        const int pc = P.pinv[col];
+        const int diag_ok = pc >= k && ((bm[pc >> 5] >> (pc & 31)) & 1u) && P.xrow[col].len != 0;
         if (diag_ok && pivrow != col) {
             int take = 0, err = 0;
             if (scheme == 1) take = 1;
-            else if (S->tol_mode == 0) take = 1;
+            else if (P.tol_mode == 0) take = 1;
             else {
                 const dig_t *num, *den; int ln, ldn;
-                const dig_t *xp = S->xd + (int64_t) pivrow * S->xcap, *xc = S->xd + (int64_t) col * S->xcap;
-                const int lp_ = slip_abs(S->xlen[pivrow]), lc_ = slip_abs(S->xlen[col]);
+                const dig_t *xp = P.xd + (int64_t) pivrow * P.xcap, *xc = P.xd + (int64_t) col * P.xcap;
+                const int lp_ = slip_abs(P.xrow[pivrow].len), lc_ = slip_abs(P.xrow[col].len);
                 if (scheme == 3) { num = xp; ln = lp_; den = xc; ldn = lc_; }   /* |small| / |diag| >= tol */
                 else             { num = xc; ln = lc_; den = xp; ldn = lp_; }   /* |diag| / |large| >= tol */
-                /* num >= tol_m * 2^tol_e * den */
                 const int Wm = ldn + 2;
                 if (Wm > wcap) err = 1;
                 else {
-                    if (lane == 0) { b2[0] = (uint32_t) S->tol_m; b2[1] = (uint32_t)(S->tol_m >> 32); }
+                    if (lane == 0) { b2[0] = (uint32_t) P.tol_m; b2[1] = (uint32_t)(P.tol_m >> 32); }
                     slip_wave_sync();
                     wb_mul_lo(b0, b2, 2, den, ldn, Wm);
-                    int lm_ = wb_len(b0, Wm);
-                    /* copy product out of b0 because slip_ge_shifted uses b0,b1 */
+                    const int lm_ = wb_len(b0, Wm);
                     for (int c = lane; c < lm_; c += SLIP_WAVE) b2[c] = b0[c];
                     slip_wave_sync();
-                    const int te = S->tol_e;
+                    const int te = P.tol_e;
                     take = slip_ge_shifted(num, ln, te < 0 ? -te : 0, b2, lm_, te > 0 ? te : 0, b0, b1, wcap, &err);
                 }
             }
@@ -498,84 +798,81 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
             if (take) pivrow = col;
         }
     }
-    const int pivpos = S->pinv[pivrow];               /* pre-swap position, >= k */
+    const int pivpos = P.pinv[pivrow];                /* pre-swap position, >= k */
     SLIP_STAMP(4);
 
     /* ---- phase 6: append U(:,k) and L(:,k) (SLIP_LU_factorize.c:226-263) ---- */
     /* U(:,k): pattern rows below k in order, then the pivot.  L(:,k): rows at or above k in order. */
-    const int nUe = nU + 1;
-    uint64_t limbsU = 0, limbsL = 0;
-    for (int t = tid; t < nUe; t += T) {
-        const int r = t < nU ? S->row_perm[S->pat[t]] : pivrow;
-        limbsU += (uint64_t)((slip_abs(S->xlen[r]) + 1) >> 1);
-    }
-    for (int t = tid; t < nL; t += T) limbsL += (uint64_t)((slip_abs(S->xlen[S->row_perm[S->pat[nU + t]]]) + 1) >> 1);
-    uint64_t totU, totL;
-    (void) slip_block_scan(limbsU, scan_tmp, &totU);
-    (void) slip_block_scan(limbsL, scan_tmp, &totL);
-    if (S->Unz + nUe > S->Ucap_nz || S->Unl + (int64_t) totU > S->Ucap_nl) return SLIPDEV_GROW_U;
-    if (S->Lnz + nL > S->Lcap_nz || S->Lnl + (int64_t) totL > S->Lcap_nl) return SLIPDEV_GROW_L;
-
-    /* offsets: tiles of T entries, running base */
-    {
-        int64_t base = S->Unl;
-        for (int t0 = 0; t0 < nUe; t0 += T) {
-            const int t = t0 + tid;
-            int r = -1; uint64_t l = 0;
-            if (t < nUe) { r = t < nU ? S->row_perm[S->pat[t]] : pivrow; l = (uint64_t)((slip_abs(S->xlen[r]) + 1) >> 1); }
-            uint64_t tt; uint64_t e = slip_block_scan(l, scan_tmp, &tt);
-            if (t < nUe) { const int64_t at = S->Unz + t; S->Ui[at] = r; S->Ulen[at] = S->xlen[r]; S->Uoff[at] = base + (int64_t) e; }
-            base += (int64_t) tt;
+    const int nUe = nU + 1, nE = nUe + nL;
+    const int64_t Lnz = sv64[SV_LNZ / 2], Lnl = sv64[SV_LNL / 2], Unz = sv64[SV_UNZ / 2], Unl = sv64[SV_UNL / 2];
+    uint64_t baseU = 0, baseL = 0;
+    for (int e0 = 0; e0 < nE; e0 += T) {
+        const int e = e0 + tid;
+        int r = -1; uint64_t lu = 0, ll = 0; SlipRow xr; xr.len = 0; xr.bits = 0; xr.h = 0; xr.pad = 0;
+        if (e < nE) {
+            r = e < nU ? P.row_perm[P.pat[e]] : (e == nU ? pivrow : P.row_perm[P.pat[e - 1]]);
+            xr = P.xrow[r];
+            if (e < nUe) lu = (uint64_t) slip_limbs(xr.len); else ll = (uint64_t) slip_limbs(xr.len);
         }
-        base = S->Lnl;
-        for (int t0 = 0; t0 < nL; t0 += T) {
-            const int t = t0 + tid;
-            int r = -1; uint64_t l = 0;
-            if (t < nL) { r = S->row_perm[S->pat[nU + t]]; l = (uint64_t)((slip_abs(S->xlen[r]) + 1) >> 1); }
-            uint64_t tt; uint64_t e = slip_block_scan(l, scan_tmp, &tt);
-            if (t < nL) { const int64_t at = S->Lnz + t; S->Li[at] = r; S->Llen[at] = S->xlen[r]; S->Loff[at] = base + (int64_t) e; }
-            base += (int64_t) tt;
+        uint64_t eu, el, tu, tl;
+        slip_block_scan2(lu, ll, scan_tmp, &eu, &el, &tu, &tl);
+        if (e < nE) {
+            /* capacity is verified before anything is committed; these records are provisional */
+            if (e < nUe) {
+                const int64_t at = Unz + e;
+                if (at < P.Ucap_nz) { P.Ui[at] = r; SlipEnt en; en.off = Unl + (int64_t)(baseU + eu); en.len = xr.len; en.bits = xr.bits; P.Ue[at] = en; }
+            } else {
+                const int64_t at = Lnz + (e - nUe);
+                if (at < P.Lcap_nz) { P.Li[at] = r; SlipEnt en; en.off = Lnl + (int64_t)(baseL + el); en.len = xr.len; en.bits = xr.bits; P.Le[at] = en; }
+            }
         }
+        baseU += tu; baseL += tl;
     }
+    const uint64_t totU = baseU, totL = baseL;
+    if (Unz + nUe > P.Ucap_nz || Unl + (int64_t) totU > P.Ucap_nl) return SLIPDEV_GROW_U;
+    if (Lnz + nL > P.Lcap_nz || Lnl + (int64_t) totL > P.Lcap_nl) return SLIPDEV_GROW_L;
     slip_block_sync();
     SLIP_STAMP(5);
     /* limbs: one wave per entry, coalesced */
-    for (int t = wave; t < nUe + nL; t += nw) {
-        const int isU = t < nUe;
-        const int64_t at = isU ? S->Unz + t : S->Lnz + (t - nUe);
-        const int r = isU ? S->Ui[at] : S->Li[at];
-        dig_t *dst = isU ? (dig_t *)(S->Ulimbs + S->Uoff[at]) : (dig_t *)(S->Llimbs + S->Loff[at]);
-        wb_copy_pad(dst, S->xd + (int64_t) r * S->xcap, slip_abs(S->xlen[r]));
+    for (int e = wave; e < nE; e += nw) {
+        const int isU = e < nUe;
+        const int64_t at = isU ? Unz + e : Lnz + (e - nUe);
+        const int r = isU ? P.Ui[at] : P.Li[at];
+        const SlipEnt en = isU ? P.Ue[at] : P.Le[at];
+        dig_t *dst = isU ? (dig_t *)(P.Ulimbs + en.off) : (dig_t *)(P.Llimbs + en.off);
+        wb_copy_pad(dst, P.xd + (int64_t) r * P.xcap, slip_abs(en.len));
     }
     slip_block_sync();
     SLIP_STAMP(6);
     /* pivot bookkeeping (slip_get_pivot.c:164-182); wave 0 */
     if (wave == 0) {
-        const int64_t pat_at = S->Lnz + (int64_t) best;       /* valid only when pivrow was the searched best */
-        int64_t at = pat_at;
-        if (S->Li[at] != pivrow) {                            /* diagonal override: find it in L(:,k) */
-            int found = -1;
+        /* position of the pivot inside L(:,k): `best` unless the diagonal was preferred */
+        int found = best;
+        if (P.Li[Lnz + best] != pivrow) {
+            found = -1;
             for (int t0 = 0; t0 < nL && found < 0; t0 += SLIP_WAVE) {
-                int t = t0 + lane;
-                uint64_t hit = slip_ballot(t < nL && S->Li[S->Lnz + t] == pivrow);
+                const int t = t0 + lane;
+                const uint64_t hit = slip_ballot(t < nL && P.Li[Lnz + t] == pivrow);
                 if (hit) found = t0 + slip_ctz64(hit);
             }
-            at = S->Lnz + found;
         }
-        const int lp_ = slip_abs(S->Llen[at]);
-        const dig_t *pv = (const dig_t *)(S->Llimbs + S->Loff[at]);
+        const SlipEnt pe = P.Le[Lnz + found];
+        const int lp_ = slip_abs(pe.len);
+        const dig_t *pv = (const dig_t *)(P.Llimbs + pe.off);
         const int z = wb_ctz(pv, lp_);
-        const int bits = wb_bits(pv, lp_);
         if (lane == 0) {
-            S->rho_off[k] = S->Loff[at]; S->rho_len[k] = S->Llen[at];
-            S->rho_bits[k] = bits; S->rho_ctz[k] = z; S->invlen[k] = 0;
-            const int intermed = pivpos, intermed2 = S->row_perm[k];
-            S->row_perm[k] = pivrow; S->row_perm[intermed] = intermed2;
-            S->pinv[pivrow] = k; S->pinv[intermed2] = intermed;
-            S->Unz += nUe; S->Unl += (int64_t) totU; S->Lnz += nL; S->Lnl += (int64_t) totL;
-            S->Up[k + 1] = S->Unz; S->Lp[k + 1] = S->Lnz;
-            S->c_write += 4ull * (unsigned long long)(nUe + nL) + 8ull * (totU + totL) + 8ull * ((lp_ + 1) >> 1);
-            if ((unsigned long long) maxdig > S->c_maxdig) S->c_maxdig = (unsigned long long) maxdig;
+            SlipPiv pr; pr.off = pe.off; pr.len = pe.len; pr.bits = pe.bits; pr.ctz = z; pr.invlen = 0;
+            pr.lo = *(const uint64_t *) pv; pr.inv64 = 0; pr.pad = 0;
+            if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
+            P.piv[k] = pr;
+            const int intermed = pivpos, intermed2 = P.row_perm[k];
+            P.row_perm[k] = pivrow; P.row_perm[intermed] = intermed2;
+            P.pinv[pivrow] = k; P.pinv[intermed2] = intermed;
+            sv64[SV_UNZ / 2] = Unz + nUe; sv64[SV_UNL / 2] = Unl + (int64_t) totU;
+            sv64[SV_LNZ / 2] = Lnz + nL;  sv64[SV_LNL / 2] = Lnl + (int64_t) totL;
+            P.Up[k + 1] = Unz + nUe; P.Lp[k + 1] = Lnz + nL;
+            st->c_write += 4ull * (unsigned long long) nE + 8ull * (totU + totL) + 8ull * slip_limbs(pe.len);
+            if ((unsigned long long) maxdig > st->c_maxdig) st->c_maxdig = (unsigned long long) maxdig;
         }
     }
     *t_read += c_read; *t_upd += c_upd; *t_src += c_src; *t_str += c_str;
@@ -585,28 +882,31 @@ SLIP_DEV int slip_do_column(SlipDev *S, const int k, uint32_t *lds,
 }
 
 /* the kernel body: columns [k_next, k_stop) on ONE workgroup */
-SLIP_DEV void slip_factor_columns(SlipDev *S, uint32_t *lds)
+template <bool BM_LDS, bool SCR_LDS>
+SLIP_DEV void slip_factor_columns(const SlipParams &P, SlipState *st, uint32_t *lds)
 {
     unsigned long long t_read = 0, t_upd = 0, t_src = 0, t_str = 0;
-    int k = S->k_next;
-    const int k_stop = S->k_stop;
+    volatile int64_t *sv64 = (volatile int64_t *)(lds + SLIP_LDS_VARS);
+    int k = st->k_next;
+    if (slip_tid() == 0) {
+        sv64[SV_LNZ / 2] = st->Lnz; sv64[SV_LNL / 2] = st->Lnl; sv64[SV_UNZ / 2] = st->Unz; sv64[SV_UNL / 2] = st->Unl;
+    }
     int status = SLIPDEV_OK;
     slip_block_sync();
-    for (; k < k_stop; k++) {
-        status = slip_do_column(S, k, lds, &t_read, &t_upd, &t_src, &t_str);
+    for (; k < P.k_stop; k++) {
+        status = slip_do_column<BM_LDS, SCR_LDS>(P, st, k, lds, &t_read, &t_upd, &t_src, &t_str);
         if (status != SLIPDEV_OK) break;
     }
     slip_block_sync();
     /* per-thread counters -> totals */
     uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
-    uint64_t a, b, c, d;
-    (void) slip_block_scan(t_read, scan_tmp, &a);
-    (void) slip_block_scan(t_upd, scan_tmp, &b);
-    (void) slip_block_scan(t_src, scan_tmp, &c);
-    (void) slip_block_scan(t_str, scan_tmp, &d);
+    uint64_t e0, e1, a, b, c, d;
+    slip_block_scan2(t_read, t_upd, scan_tmp, &e0, &e1, &a, &b);
+    slip_block_scan2(t_src, t_str, scan_tmp, &e0, &e1, &c, &d);
     if (slip_tid() == 0) {
-        S->c_read += a; S->c_upd += b; S->c_src += c; S->c_streamed += d;
-        S->k_next = k; S->status = status; S->status_k = k;
+        st->c_read += a; st->c_upd += b; st->c_src += c; st->c_streamed += d;
+        st->Lnz = sv64[SV_LNZ / 2]; st->Lnl = sv64[SV_LNL / 2]; st->Unz = sv64[SV_UNZ / 2]; st->Unl = sv64[SV_UNL / 2];
+        st->k_next = k; st->status = status; st->status_k = k;
     }
 }
 

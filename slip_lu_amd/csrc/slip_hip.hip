@@ -31,11 +31,13 @@
 /* kernels                                                             */
 /* ------------------------------------------------------------------ */
 #ifndef SLIP_EMULATE
-extern "C" __global__ void __launch_bounds__(1024)
-slip_factor_kernel(SlipDev *S)
+#define SLIP_MAX_WAVES 8                   /* 512 threads: 2 waves per SIMD, 256 VGPRs per lane */
+template <bool BM_LDS, bool SCR_LDS>
+__global__ void __launch_bounds__(64 * SLIP_MAX_WAVES)
+slip_factor_kernel(SlipParams P, SlipState *st)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t slip_lds[];
-    slip_factor_columns(S, slip_lds);
+    slip_factor_columns<BM_LDS, SCR_LDS>(P, st, slip_lds);
 }
 
 /* unit-test kernel: block b performs operation b with one wavefront */
@@ -51,6 +53,30 @@ slip_wave_op_kernel(int op, int la, int lb, int W, const uint32_t *a, const uint
     else if (op == 2) wb_addsub(O, A, la, B, lb, W, 1);
     else wb_inv_extend(O, 0, W, A, la, s0, s1);
 }
+
+/* micro-benchmark kernel (development aid): cycles per wave-level primitive, nwaves waves busy */
+extern "C" __global__ void __launch_bounds__(512)
+slip_wave_bench_kernel(int op, int la, int lb, int W, int iters, int out_in_lds,
+                       const uint32_t *a, const uint32_t *b, uint32_t *gout, unsigned long long *cycles)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t slip_lds[];
+    const int wave = slip_wave();
+    uint32_t *O = out_in_lds ? slip_lds + wave * 2 * (W + 2) : gout + (int64_t) wave * 2 * (W + 2);
+    uint32_t *O2 = O + W + 2;
+    const uint32_t *A = a + (int64_t) wave * la, *B = b + (int64_t) wave * lb;
+    __syncthreads();
+    unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; it++) {
+        if (op == 0) wb_mul_lo(O, A, la, B, lb, W);
+        else if (op == 1) wb_addsub(O, A, la, B, lb, W, 1);
+        else if (op == 2) { int l = wb_len(B, lb); if (l == 12345) O[0] = 1; }
+        else if (op == 3) wb_copy_shr(O, B, lb, 3, W);
+        else if (op == 4) { wb_mul_lo(O, A, la, B, lb, W); wb_mul_lo(O2, O, W, A, la, W); }
+        else if (op == 5) slip_wave_sync();
+    }
+    unsigned long long t1 = clock64();
+    if (slip_lane() == 0) cycles[wave] = (t1 - t0) / (unsigned long long) iters;
+}
 #else
 static uint32_t slip_emu_lds[SLIP_LDS_MAX_WORDS + 1024];
 #endif
@@ -59,14 +85,15 @@ static uint32_t slip_emu_lds[SLIP_LDS_MAX_WORDS + 1024];
 /* host state                                                          */
 /* ------------------------------------------------------------------ */
 struct slip_hip_factor {
-    SlipDev h;            /* host mirror (device pointers inside) */
-    SlipDev *d;           /* device copy the kernel works on      */
+    SlipParams P;         /* kernel arguments (device pointers inside)   */
+    SlipState hs;         /* host mirror of the mutable device state     */
+    SlipState *ds;        /* device copy the kernel works on             */
     int32_t n; int64_t annz, alimbs;
-    int32_t waves, lds_words;
+    int32_t waves, lds_words, bitmap_in_lds, scratch_in_lds;
     int32_t last_status, window_end, launches;
     double kernel_ms;
     hipEvent_t ev0, ev1;
-    /* owned device arrays that are not reachable through const pointers in h */
+    /* owned device arrays that are only reachable through const pointers in P */
     int64_t *dAp; int32_t *dAi, *dAlen; int64_t *dAoff; uint64_t *dAlimbs; int32_t *dq;
 };
 
@@ -117,54 +144,52 @@ extern "C" int slip_hip_matgen(int32_t n, double density, int32_t bits, uint64_t
 /* choose waves / LDS split for the current xcap */
 static void plan_launch(slip_hip_factor *f)
 {
-    SlipDev *h = &f->h;
-    h->wcap = h->xcap + 8;
-    h->bm_words = (h->n + 31) / 32;
-    h->bitmap_in_lds = h->bm_words <= SLIP_BITMAP_LDS_MAX_WORDS;
-    int fixed = SLIP_LDS_BITMAP + (h->bitmap_in_lds ? h->bm_words : 0);
+    SlipParams *P = &f->P;
+    P->wcap = P->xcap + 8;
+    P->bm_words = (P->n + 31) / 32;
+    f->bitmap_in_lds = P->bm_words <= SLIP_BITMAP_LDS_MAX_WORDS;
+    int fixed = SLIP_LDS_BITMAP + (f->bitmap_in_lds ? P->bm_words : 0);
     int nw = f->waves;
-    while (nw > 4 && fixed + (int64_t) nw * 3 * h->wcap > SLIP_LDS_MAX_WORDS) nw /= 2;
-    h->scratch_in_lds = fixed + (int64_t) nw * 3 * h->wcap <= SLIP_LDS_MAX_WORDS;
+    /* per wave 3 scratch buffers of wcap digits, plus one workgroup-shared buffer */
+    while (nw > 4 && fixed + (int64_t)(nw * 3 + 1) * P->wcap > SLIP_LDS_MAX_WORDS) nw /= 2;
+    f->scratch_in_lds = fixed + (int64_t)(nw * 3 + 1) * P->wcap <= SLIP_LDS_MAX_WORDS;
     f->waves = nw;
-    f->lds_words = fixed + (h->scratch_in_lds ? nw * 3 * h->wcap : 0);
+    f->lds_words = fixed + (f->scratch_in_lds ? (nw * 3 + 1) * P->wcap : 0);
 }
 
 static int alloc_x(slip_hip_factor *f, int32_t xcap)
 {
-    SlipDev *h = &f->h;
-    if (h->xd) hipFree(h->xd);
-    if (h->invd) hipFree(h->invd);
-    if (h->gscratch) hipFree(h->gscratch);
-    h->xd = NULL; h->invd = NULL; h->gscratch = NULL;
-    xcap = (xcap + 1) & ~1;
-    h->xcap = xcap; h->invcap = xcap + 8;
-    if (dev_alloc(&h->xd, (int64_t) h->n * xcap)) return SLIP_HIP_OUT_OF_MEMORY;
-    if (dev_alloc(&h->invd, (int64_t) h->n * h->invcap)) return SLIP_HIP_OUT_OF_MEMORY;
-    if (hipMemset(h->invlen, 0, (size_t) h->n * 4) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
+    SlipParams *P = &f->P;
+    if (P->xd) hipFree(P->xd);
+    if (P->invd) hipFree(P->invd);
+    if (P->gscratch) hipFree(P->gscratch);
+    P->xd = NULL; P->invd = NULL; P->gscratch = NULL;
+    xcap = (xcap + 3) & ~3;
+    P->xcap = xcap; P->invcap = xcap + 8;
+    if (dev_alloc(&P->xd, (int64_t) P->n * xcap)) return SLIP_HIP_OUT_OF_MEMORY;
+    if (dev_alloc(&P->invd, (int64_t) P->n * P->invcap)) return SLIP_HIP_OUT_OF_MEMORY;
+    /* cached inverses are gone: pivots recompute them on demand (invlen = 0) */
+    if (hipMemset(P->piv, 0, (size_t) P->n * sizeof(SlipPiv)) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
     plan_launch(f);
-    if (dev_alloc(&h->gscratch, (int64_t) 16 * 3 * h->wcap)) return SLIP_HIP_OUT_OF_MEMORY;
+    if (dev_alloc(&P->gscratch, (int64_t) 16 * 3 * P->wcap)) return SLIP_HIP_OUT_OF_MEMORY;
     return 0;
 }
 
 extern "C" int slip_hip_factor_reset(slip_hip_factor *f)
 {
     if (!f) return SLIP_HIP_INCORRECT_INPUT;
-    SlipDev *h = &f->h;
+    SlipParams *P = &f->P;
     const int32_t n = f->n;
     int32_t *id = (int32_t *) malloc((size_t) n * 4);
     if (!id) return SLIP_HIP_OUT_OF_MEMORY;
     for (int32_t i = 0; i < n; i++) id[i] = i;
-    CK(hipMemcpy(h->pinv, id, (size_t) n * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(h->row_perm, id, (size_t) n * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(P->pinv, id, (size_t) n * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(P->row_perm, id, (size_t) n * 4, hipMemcpyHostToDevice));
     free(id);
-    CK(hipMemset(h->h, 0xFF, (size_t) n * 4));
-    CK(hipMemset(h->invlen, 0, (size_t) n * 4));
-    CK(hipMemset(h->Lp, 0, 8));
-    CK(hipMemset(h->Up, 0, 8));
-    h->Lnz = h->Lnl = h->Unz = h->Unl = 0;
-    h->k_next = 0; h->status = 0; h->status_k = 0;
-    h->c_upd = h->c_read = h->c_write = h->c_src = h->c_streamed = h->c_maxdig = 0;
-    memset(h->prof, 0, sizeof h->prof);
+    CK(hipMemset(P->Lp, 0, 8));
+    CK(hipMemset(P->Up, 0, 8));
+    memset(&f->hs, 0, sizeof f->hs);
+    CK(hipMemcpy(f->ds, &f->hs, sizeof(SlipState), hipMemcpyHostToDevice));
     f->last_status = 0; f->window_end = 0; f->kernel_ms = 0; f->launches = 0;
     return SLIP_HIP_OK;
 }
@@ -172,15 +197,14 @@ extern "C" int slip_hip_factor_reset(slip_hip_factor *f)
 extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
 {
     if (!f) return;
-    SlipDev *h = &f->h;
+    SlipParams *P = &f->P;
     hipFree(f->dAp); hipFree(f->dAi); hipFree(f->dAlen); hipFree(f->dAoff); hipFree(f->dAlimbs); hipFree(f->dq);
-    hipFree(h->pinv); hipFree(h->row_perm); hipFree(h->h); hipFree(h->xd); hipFree(h->xlen);
-    hipFree(h->rho_off); hipFree(h->rho_len); hipFree(h->rho_bits); hipFree(h->rho_ctz);
-    hipFree(h->invd); hipFree(h->invlen);
-    hipFree(h->Lp); hipFree(h->Li); hipFree(h->Llen); hipFree(h->Loff); hipFree(h->Llimbs);
-    hipFree(h->Up); hipFree(h->Ui); hipFree(h->Ulen); hipFree(h->Uoff); hipFree(h->Ulimbs);
-    hipFree(h->pat); hipFree(h->gscratch); hipFree(h->gbitmap);
-    hipFree(f->d);
+    hipFree(P->pinv); hipFree(P->row_perm); hipFree(P->xrow); hipFree(P->xd);
+    hipFree(P->piv); hipFree(P->invd);
+    hipFree(P->Lp); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
+    hipFree(P->Up); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
+    hipFree(P->pat); hipFree(P->gscratch); hipFree(P->gbitmap);
+    hipFree(f->ds);
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
     free(f);
@@ -254,38 +278,40 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
 
     slip_hip_factor *f = (slip_hip_factor *) calloc(1, sizeof(slip_hip_factor));
     if (!f) { free(hAp); free(hAi); free(hAlen); free(hAoff); free(hAlimbs); return SLIP_HIP_OUT_OF_MEMORY; }
-    SlipDev *h = &f->h;
+    SlipParams *P = &f->P;
     f->n = n; f->annz = onz; f->alimbs = ol;
-    f->waves = opt.waves > 0 ? opt.waves : 16;
-    if (f->waves > 16) f->waves = 16;
-    h->n = n; h->pivot_scheme = opt.pivot; h->limb_cap = opt.limb_cap;
-    if (!(opt.tol > 0)) { h->tol_mode = 0; h->tol_m = 0; h->tol_e = 0; }
+    f->waves = opt.waves > 0 ? opt.waves : 8;
+#ifndef SLIP_MAX_WAVES
+#define SLIP_MAX_WAVES 16                  /* emulation build */
+#endif
+    if (f->waves > SLIP_MAX_WAVES) f->waves = SLIP_MAX_WAVES;
+    P->n = n; P->pivot_scheme = opt.pivot; P->limb_cap = opt.limb_cap;
+    if (!(opt.tol > 0)) { P->tol_mode = 0; P->tol_m = 0; P->tol_e = 0; }
     else {
         int e; double fr = frexp(opt.tol, &e);            /* mpq_set_d takes the double exactly */
-        h->tol_mode = 1; h->tol_m = (uint64_t) ldexp(fr, 53); h->tol_e = e - 53;
+        P->tol_mode = 1; P->tol_m = (uint64_t) ldexp(fr, 53); P->tol_e = e - 53;
     }
     int rc = 0;
 #define A_(call) do { if (!rc) rc = (call); } while (0)
     A_(dev_alloc(&f->dAp, (int64_t) n + 1)); A_(dev_alloc(&f->dAi, onz)); A_(dev_alloc(&f->dAlen, onz));
     A_(dev_alloc(&f->dAoff, onz)); A_(dev_alloc(&f->dAlimbs, ol)); A_(dev_alloc(&f->dq, n));
-    A_(dev_alloc(&h->pinv, n)); A_(dev_alloc(&h->row_perm, n)); A_(dev_alloc(&h->h, n)); A_(dev_alloc(&h->xlen, n));
-    A_(dev_alloc(&h->rho_off, n)); A_(dev_alloc(&h->rho_len, n)); A_(dev_alloc(&h->rho_bits, n)); A_(dev_alloc(&h->rho_ctz, n));
-    A_(dev_alloc(&h->invlen, n)); A_(dev_alloc(&h->pat, n));
-    A_(dev_alloc(&h->gbitmap, (int64_t)(n + 31) / 32 + 64));
+    A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n)); A_(dev_alloc(&P->xrow, n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->pat, n));
+    A_(dev_alloc(&P->gbitmap, (int64_t)(n + 31) / 32 + 64));
     /* initial sizes: S->lnz/unz only size the first allocation in the reference too */
-    h->Lcap_nz = opt.lnz_hint > 0 ? opt.lnz_hint : 4 * onz + n;
-    h->Ucap_nz = opt.unz_hint > 0 ? opt.unz_hint : 4 * onz + n;
-    if (h->Lcap_nz < n) h->Lcap_nz += n;
-    if (h->Ucap_nz < n) h->Ucap_nz += n;
+    P->Lcap_nz = opt.lnz_hint > 0 ? opt.lnz_hint : 4 * onz + n;
+    P->Ucap_nz = opt.unz_hint > 0 ? opt.unz_hint : 4 * onz + n;
+    if (P->Lcap_nz < n) P->Lcap_nz += n;
+    if (P->Ucap_nz < n) P->Ucap_nz += n;
     const int32_t cap_digits = opt.limb_cap > 0 ? 2 * opt.limb_cap + 8 : 0;
     int32_t xcap0 = cap_digits > 0 ? cap_digits : (2 * maxdig + 8 > 16 ? 2 * maxdig + 8 : 16);
-    h->Lcap_nl = h->Lcap_nz * (int64_t)(opt.limb_cap > 0 ? (opt.limb_cap + 1) / 2 + 1 : 2);
-    h->Ucap_nl = h->Ucap_nz * 2;
-    A_(dev_alloc(&h->Lp, (int64_t) n + 1)); A_(dev_alloc(&h->Li, h->Lcap_nz)); A_(dev_alloc(&h->Llen, h->Lcap_nz));
-    A_(dev_alloc(&h->Loff, h->Lcap_nz)); A_(dev_alloc(&h->Llimbs, h->Lcap_nl));
-    A_(dev_alloc(&h->Up, (int64_t) n + 1)); A_(dev_alloc(&h->Ui, h->Ucap_nz)); A_(dev_alloc(&h->Ulen, h->Ucap_nz));
-    A_(dev_alloc(&h->Uoff, h->Ucap_nz)); A_(dev_alloc(&h->Ulimbs, h->Ucap_nl));
-    A_(dev_alloc(&f->d, 1));
+    P->Lcap_nl = P->Lcap_nz * 2;
+    P->Ucap_nl = P->Ucap_nz * 2;
+    A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Li, P->Lcap_nz)); A_(dev_alloc(&P->Le, P->Lcap_nz));
+    A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
+    A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, P->Ucap_nz)); A_(dev_alloc(&P->Ue, P->Ucap_nz));
+    A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
+    A_(dev_alloc(&f->ds, 1));
     if (!rc) rc = alloc_x(f, xcap0);
 #undef A_
     if (!rc) {
@@ -295,11 +321,11 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
             hipMemcpy(f->dAoff, hAoff, (size_t) onz * 8, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(f->dAlimbs, hAlimbs, (size_t) ol * 8, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(f->dq, q, (size_t) n * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemset(h->xlen, 0, (size_t) n * 4) != hipSuccess)
+            hipMemset(P->xrow, 0, (size_t) n * sizeof(SlipRow)) != hipSuccess)
             rc = SLIP_HIP_DEVICE_ERROR;
     }
     free(hAp); free(hAi); free(hAlen); free(hAoff); free(hAlimbs);
-    h->Ap = f->dAp; h->Ai = f->dAi; h->Alen = f->dAlen; h->Aoff = f->dAoff; h->Alimbs = f->dAlimbs; h->q = f->dq;
+    P->Ap = f->dAp; P->Ai = f->dAi; P->Alen = f->dAlen; P->Aoff = f->dAoff; P->Alimbs = f->dAlimbs; P->q = f->dq;
     if (!rc && (hipEventCreate(&f->ev0) != hipSuccess || hipEventCreate(&f->ev1) != hipSuccess)) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc) rc = slip_hip_factor_reset(f);
     if (rc) { slip_hip_factor_destroy(f); return rc; }
@@ -309,19 +335,31 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
 
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
-    CK(hipMemcpyAsync(f->d, &f->h, sizeof(SlipDev), hipMemcpyHostToDevice, stream));
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;
-    CK(hipFuncSetAttribute((const void *) slip_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-    hipLaunchKernelGGL(slip_factor_kernel, dim3(1), dim3(64 * f->waves), lds_bytes, stream, f->d);
+    const dim3 grid(1), block(64 * f->waves);
+#define SLIP_LAUNCH(BM, SC) do { \
+        CK(hipFuncSetAttribute((const void *) slip_factor_kernel<BM, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes)); \
+        hipLaunchKernelGGL((slip_factor_kernel<BM, SC>), grid, block, lds_bytes, stream, f->P, f->ds); } while (0)
+    if (f->bitmap_in_lds && f->scratch_in_lds) SLIP_LAUNCH(true, true);
+    else if (f->bitmap_in_lds) SLIP_LAUNCH(true, false);
+    else if (f->scratch_in_lds) SLIP_LAUNCH(false, true);
+    else SLIP_LAUNCH(false, false);
+#undef SLIP_LAUNCH
     CK(hipGetLastError());
 #else
-    SlipDev *d = f->d;
-    emu::launch(1, 64 * f->waves, [d]() { slip_factor_columns(d, slip_emu_lds); });
+    const SlipParams P = f->P; SlipState *ds = f->ds;
+    const int bm = f->bitmap_in_lds, sc = f->scratch_in_lds;
+    emu::launch(1, 64 * f->waves, [P, ds, bm, sc]() {
+        if (bm && sc) slip_factor_columns<true, true>(P, ds, slip_emu_lds);
+        else if (bm) slip_factor_columns<true, false>(P, ds, slip_emu_lds);
+        else if (sc) slip_factor_columns<false, true>(P, ds, slip_emu_lds);
+        else slip_factor_columns<false, false>(P, ds, slip_emu_lds);
+    });
 #endif
     CK(hipEventRecord(f->ev1, stream));
-    CK(hipMemcpyAsync(&f->h, f->d, sizeof(SlipDev), hipMemcpyDeviceToHost, stream));
+    CK(hipMemcpyAsync(&f->hs, f->ds, sizeof(SlipState), hipMemcpyDeviceToHost, stream));
     CK(hipStreamSynchronize(stream));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, f->ev0, f->ev1));
@@ -334,10 +372,11 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
 {
     if (!f) return SLIP_HIP_INCORRECT_INPUT;
     hipStream_t stream = (hipStream_t) stream_v;
-    SlipDev *h = &f->h;
+    SlipParams *P = &f->P;
+    SlipState *h = &f->hs;
     if (kmax <= 0 || kmax > f->n) kmax = f->n;
     f->kernel_ms = 0; f->launches = 0; f->window_end = 0;
-    h->k_stop = kmax;
+    P->k_stop = kmax;
     int rc = SLIP_HIP_OK;
     while (h->k_next < kmax) {
         int e = launch_columns(f, stream);
@@ -347,18 +386,32 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
         if (h->status == SLIPDEV_WINDOW_END) { f->window_end = 1; break; }
         if (h->status == SLIPDEV_GROW_L) {
             /* the slab that ran out is the one to double (cf. slip_sparse_realloc.c) */
-            int64_t nz = h->Lcap_nz * 2, nl = h->Lcap_nl * 2;
-            if ((e = dev_grow(&h->Li, h->Lnz, nz)) || (e = dev_grow(&h->Llen, h->Lnz, nz)) ||
-                (e = dev_grow(&h->Loff, h->Lnz, nz)) || (e = dev_grow(&h->Llimbs, h->Lnl, nl))) { rc = e; break; }
-            h->Lcap_nz = nz; h->Lcap_nl = nl;
+            int64_t nz = P->Lcap_nz * 2, nl = P->Lcap_nl * 2;
+            if ((e = dev_grow(&P->Li, h->Lnz, nz)) || (e = dev_grow(&P->Le, h->Lnz, nz)) ||
+                (e = dev_grow(&P->Llimbs, h->Lnl, nl))) { rc = e; break; }
+            P->Lcap_nz = nz; P->Lcap_nl = nl;
         } else if (h->status == SLIPDEV_GROW_U) {
-            int64_t nz = h->Ucap_nz * 2, nl = h->Ucap_nl * 2;
-            if ((e = dev_grow(&h->Ui, h->Unz, nz)) || (e = dev_grow(&h->Ulen, h->Unz, nz)) ||
-                (e = dev_grow(&h->Uoff, h->Unz, nz)) || (e = dev_grow(&h->Ulimbs, h->Unl, nl))) { rc = e; break; }
-            h->Ucap_nz = nz; h->Ucap_nl = nl;
+            int64_t nz = P->Ucap_nz * 2, nl = P->Ucap_nl * 2;
+            if ((e = dev_grow(&P->Ui, h->Unz, nz)) || (e = dev_grow(&P->Ue, h->Unz, nz)) ||
+                (e = dev_grow(&P->Ulimbs, h->Unl, nl))) { rc = e; break; }
+            P->Ucap_nz = nz; P->Ucap_nl = nl;
         } else if (h->status == SLIPDEV_GROW_X) {
-            if ((int64_t) h->xcap * 2 > (1 << 28)) { rc = SLIP_HIP_OUT_OF_MEMORY; break; }
-            if ((e = alloc_x(f, h->xcap * 2))) { rc = e; break; }
+            if ((int64_t) P->xcap * 2 > (1 << 28)) { rc = SLIP_HIP_OUT_OF_MEMORY; break; }
+            /* x and the inverse cache are scratch; the pivot records must survive */
+            SlipPiv *keep = NULL;
+            const int32_t K = h->k_next;
+            if (K > 0) {
+                keep = (SlipPiv *) malloc((size_t) K * sizeof(SlipPiv));
+                if (!keep) { rc = SLIP_HIP_OUT_OF_MEMORY; break; }
+                if (hipMemcpy(keep, P->piv, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(keep); rc = SLIP_HIP_DEVICE_ERROR; break; }
+            }
+            e = alloc_x(f, P->xcap * 2);
+            if (!e && K > 0) {
+                for (int32_t k = 0; k < K; k++) keep[k].invlen = 0;
+                if (hipMemcpy(P->piv, keep, (size_t) K * sizeof(SlipPiv), hipMemcpyHostToDevice) != hipSuccess) e = SLIP_HIP_DEVICE_ERROR;
+            }
+            free(keep);
+            if (e) { rc = e; break; }
         } else { rc = SLIP_HIP_DEVICE_ERROR; break; }
     }
     f->last_status = rc;
@@ -369,31 +422,36 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
 extern "C" int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out12)
 {
     if (!f || !out12) return SLIP_HIP_INCORRECT_INPUT;
-    for (int i = 0; i < 12; i++) out12[i] = f->h.prof[i];
+    for (int i = 0; i < 12; i++) out12[i] = f->hs.prof[i];
     return SLIP_HIP_OK;
 }
 
 extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)
 {
     if (!f || !o) return SLIP_HIP_INCORRECT_INPUT;
-    const SlipDev *h = &f->h;
+    const SlipState *h = &f->hs;
     o->n = f->n; o->K = h->k_next; o->status = f->last_status; o->window_end = f->window_end;
     o->lnz = h->Lnz; o->unz = h->Unz; o->l_limbs = h->Lnl; o->u_limbs = h->Unl;
     o->n_upd = (int64_t) h->c_upd; o->b_read = (int64_t) h->c_read; o->b_write = (int64_t) h->c_write;
     o->n_src = (int64_t) h->c_src; o->l_streamed = (int64_t) h->c_streamed;
     o->max_limbs = (int64_t)((h->c_maxdig + 1) / 2);
-    o->kernel_ms = f->kernel_ms; o->launches = f->launches; o->xcap_digits = h->xcap;
+    o->kernel_ms = f->kernel_ms; o->launches = f->launches; o->xcap_digits = f->P.xcap;
     return SLIP_HIP_OK;
 }
 
-static int fetch_lens(int32_t *dst, const int32_t *dev, int64_t cnt)
+/* signed digit counts of stored entries -> signed 64-bit limb counts */
+static int fetch_lens(int32_t *dst, const SlipEnt *dev, int64_t cnt)
 {
-    if (hipMemcpy(dst, dev, (size_t) cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
-    for (int64_t t = 0; t < cnt; t++) {             /* digits -> 64-bit limbs, sign kept */
-        int32_t d = dst[t], a = d < 0 ? -d : d;
+    if (cnt <= 0) return 0;
+    SlipEnt *tmp = (SlipEnt *) malloc((size_t) cnt * sizeof(SlipEnt));
+    if (!tmp) return SLIP_HIP_OUT_OF_MEMORY;
+    if (hipMemcpy(tmp, dev, (size_t) cnt * sizeof(SlipEnt), hipMemcpyDeviceToHost) != hipSuccess) { free(tmp); return SLIP_HIP_DEVICE_ERROR; }
+    for (int64_t t = 0; t < cnt; t++) {
+        int32_t d = tmp[t].len, a = d < 0 ? -d : d;
         a = (a + 1) >> 1;
         dst[t] = d < 0 ? -a : a;
     }
+    free(tmp);
     return 0;
 }
 
@@ -404,39 +462,39 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
                                         int32_t *pinv)
 {
     if (!f) return SLIP_HIP_INCORRECT_INPUT;
-    const SlipDev *h = &f->h;
+    const SlipParams *P = &f->P;
+    const SlipState *h = &f->hs;
     const int32_t K = h->k_next;
-    if (Lp) CK(hipMemcpy(Lp, h->Lp, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost));
-    if (Up) CK(hipMemcpy(Up, h->Up, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost));
-    if (Li) CK(hipMemcpy(Li, h->Li, (size_t) h->Lnz * 4, hipMemcpyDeviceToHost));
-    if (Ui) CK(hipMemcpy(Ui, h->Ui, (size_t) h->Unz * 4, hipMemcpyDeviceToHost));
-    if (Llen && fetch_lens(Llen, h->Llen, h->Lnz)) return SLIP_HIP_DEVICE_ERROR;
-    if (Ulen && fetch_lens(Ulen, h->Ulen, h->Unz)) return SLIP_HIP_DEVICE_ERROR;
-    if (Llimbs) CK(hipMemcpy(Llimbs, h->Llimbs, (size_t) h->Lnl * 8, hipMemcpyDeviceToHost));
-    if (Ulimbs) CK(hipMemcpy(Ulimbs, h->Ulimbs, (size_t) h->Unl * 8, hipMemcpyDeviceToHost));
-    if (pinv) CK(hipMemcpy(pinv, h->pinv, (size_t) f->n * 4, hipMemcpyDeviceToHost));
-    if (rholen || rholimbs) {
-        /* the pivots live in the L slab: gather them on the host side */
-        int32_t *rl = (int32_t *) malloc((size_t)(K > 0 ? K : 1) * 4);
-        int64_t *ro = (int64_t *) malloc((size_t)(K > 0 ? K : 1) * 8);
-        if (!rl || !ro) { free(rl); free(ro); return SLIP_HIP_OUT_OF_MEMORY; }
-        if (fetch_lens(rl, h->rho_len, K) ||
-            hipMemcpy(ro, h->rho_off, (size_t) K * 8, hipMemcpyDeviceToHost) != hipSuccess) { free(rl); free(ro); return SLIP_HIP_DEVICE_ERROR; }
+    int e;
+    if (Lp) CK(hipMemcpy(Lp, P->Lp, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost));
+    if (Up) CK(hipMemcpy(Up, P->Up, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost));
+    if (Li && h->Lnz) CK(hipMemcpy(Li, P->Li, (size_t) h->Lnz * 4, hipMemcpyDeviceToHost));
+    if (Ui && h->Unz) CK(hipMemcpy(Ui, P->Ui, (size_t) h->Unz * 4, hipMemcpyDeviceToHost));
+    if (Llen && (e = fetch_lens(Llen, P->Le, h->Lnz))) return e;
+    if (Ulen && (e = fetch_lens(Ulen, P->Ue, h->Unz))) return e;
+    if (Llimbs && h->Lnl) CK(hipMemcpy(Llimbs, P->Llimbs, (size_t) h->Lnl * 8, hipMemcpyDeviceToHost));
+    if (Ulimbs && h->Unl) CK(hipMemcpy(Ulimbs, P->Ulimbs, (size_t) h->Unl * 8, hipMemcpyDeviceToHost));
+    if (pinv) CK(hipMemcpy(pinv, P->pinv, (size_t) f->n * 4, hipMemcpyDeviceToHost));
+    if ((rholen || rholimbs) && K > 0) {
+        /* the pivots live in the L slab: gather them through the pivot records */
+        SlipPiv *pr = (SlipPiv *) malloc((size_t) K * sizeof(SlipPiv));
+        if (!pr) return SLIP_HIP_OUT_OF_MEMORY;
+        if (hipMemcpy(pr, P->piv, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(pr); return SLIP_HIP_DEVICE_ERROR; }
         int64_t o = 0, capl = rho_limbs_inout ? *rho_limbs_inout : 0;
         int rc = 0;
         for (int32_t k = 0; k < K && !rc; k++) {
-            int32_t l = rl[k] < 0 ? -rl[k] : rl[k];
-            if (rholen) rholen[k] = rl[k];
+            int32_t d = pr[k].len, l = ((d < 0 ? -d : d) + 1) >> 1;
+            if (rholen) rholen[k] = d < 0 ? -l : l;
             if (rholimbs) {
                 if (o + l > capl) { rc = SLIP_HIP_INCORRECT_INPUT; break; }
-                if (hipMemcpy(rholimbs + o, h->Llimbs + ro[k], (size_t) l * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+                if (hipMemcpy(rholimbs + o, P->Llimbs + pr[k].off, (size_t) l * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
             }
             o += l;
         }
         if (rho_limbs_inout) *rho_limbs_inout = o;
-        free(rl); free(ro);
+        free(pr);
         if (rc) return rc;
-    }
+    } else if (rho_limbs_inout) *rho_limbs_inout = 0;
     return SLIP_HIP_OK;
 }
 
@@ -471,3 +529,24 @@ extern "C" int slip_hip_wave_op_test(int32_t op, int32_t nops, int32_t la, int32
     hipFree(da); hipFree(db); hipFree(dout); hipFree(ds);
     return SLIP_HIP_OK;
 }
+
+#ifndef SLIP_EMULATE
+/* development aid: average shader cycles of one wave-level primitive (see slip_wave_bench_kernel) */
+extern "C" int slip_hip_wave_op_bench(int32_t op, int32_t la, int32_t lb, int32_t W, int32_t iters, int32_t nwaves,
+                                      int32_t out_in_lds, unsigned long long *cycles_out)
+{
+    uint32_t *da = NULL, *db = NULL, *dout = NULL; unsigned long long *dc = NULL;
+    if (dev_alloc(&da, (int64_t) nwaves * la) || dev_alloc(&db, (int64_t) nwaves * lb) ||
+        dev_alloc(&dout, (int64_t) nwaves * 2 * (W + 2)) || dev_alloc(&dc, nwaves)) return SLIP_HIP_OUT_OF_MEMORY;
+    CK(hipMemset(da, 0x5A, (size_t) nwaves * la * 4));
+    CK(hipMemset(db, 0xC3, (size_t) nwaves * lb * 4));
+    const size_t lds = (size_t) nwaves * 2 * (W + 2) * 4;
+    CK(hipFuncSetAttribute((const void *) slip_wave_bench_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipLaunchKernelGGL(slip_wave_bench_kernel, dim3(1), dim3(64 * nwaves), lds, 0, op, la, lb, W, iters, out_in_lds, da, db, dout, dc);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(cycles_out, dc, (size_t) nwaves * 8, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dout); hipFree(dc);
+    return SLIP_HIP_OK;
+}
+#endif

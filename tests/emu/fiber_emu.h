@@ -32,6 +32,8 @@ struct State {
     std::vector<WaveCtx> waves;
     ucontext_t sched;
     int bar_arrived = 0; unsigned bar_gen = 0; int bar_site = 0;
+    std::vector<int> last_site;          /* per thread: line of the cross-lane op it last entered (-line: barrier) */
+    unsigned long progress = 0;          /* bumped whenever a collective / barrier completes or a thread ends */
     std::function<void()> body;
 };
 
@@ -57,8 +59,10 @@ inline const uint64_t *collective(uint64_t v, int site)
     int lane = s.cur & 63;
     WaveCtx &w = s.waves[s.cur >> 6];
     unsigned g = w.gen;
+    s.last_site[s.cur] = site;
     w.vals[lane] = v; w.site[lane] = site;
     if (++w.arrived == 64) {
+        s.progress++;
         for (int i = 0; i < 64; i++) {
             if (w.site[i] != site) die("wave divergence at cross-lane op, lines", w.site[i], site);
             w.out[i] = w.vals[i];
@@ -88,9 +92,10 @@ inline void block_sync(int site)
 {
     State &s = S();
     unsigned g = s.bar_gen;
+    s.last_site[s.cur] = -site;
     if (s.bar_arrived == 0) s.bar_site = site;
     else if (s.bar_site != site) die("threads at different barriers, lines", s.bar_site, site);
-    if (++s.bar_arrived == s.nthreads) { s.bar_arrived = 0; s.bar_gen++; }
+    if (++s.bar_arrived == s.nthreads) { s.bar_arrived = 0; s.bar_gen++; s.progress++; }
     else while (s.bar_gen == g) yield_();
 }
 
@@ -108,7 +113,7 @@ inline void launch(int nblocks, int nthreads_, std::function<void()> body, size_
     State &s = S();
     if (nthreads_ % 64) die("block size must be a multiple of 64", nthreads_, 64);
     s.nthreads = nthreads_; s.nblocks = nblocks; s.body = body;
-    s.ctx.resize(nthreads_); s.done.assign(nthreads_, 0);
+    s.ctx.resize(nthreads_); s.done.assign(nthreads_, 0); s.last_site.assign(nthreads_, 0);
     s.waves.assign(nthreads_ / 64, WaveCtx());
     if ((int) s.stacks.size() < nthreads_) {
         size_t old = s.stacks.size();
@@ -127,14 +132,25 @@ inline void launch(int nblocks, int nthreads_, std::function<void()> body, size_
             s.done[t] = 0;
         }
         int remaining = nthreads_;
+        unsigned long seen = s.progress; int idle = 0;
         while (remaining > 0) {
             int progressed = 0;
+            /* deadlock detector: whole passes over the fibers without any collective completing */
+            if (s.progress != seen) { seen = s.progress; idle = 0; }
+            else if (++idle > 4) {
+                fprintf(stderr, "fiber_emu: DEADLOCK in block %d -- threads wait at different cross-lane ops "
+                                "(line, negative = block barrier):\n", b);
+                for (int t = 0; t < nthreads_; t++)
+                    if (!s.done[t] && (t % 64 == 0 || s.last_site[t] != s.last_site[t - 1]))
+                        fprintf(stderr, "  thread %d.. : %d\n", t, s.last_site[t]);
+                abort();
+            }
             for (int t = 0; t < nthreads_; t++) {
                 if (s.done[t]) continue;
                 s.cur = t;
                 swapcontext(&s.sched, &s.ctx[t]);
                 progressed = 1;
-                if (s.done[t]) remaining--;
+                if (s.done[t]) { remaining--; s.progress++; }
             }
             if (!progressed) break;
         }
