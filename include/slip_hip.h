@@ -45,6 +45,9 @@ typedef struct slip_hip_options {
     int32_t waves;        /* waves per workgroup (0 = default 16)                      */
     int64_t lnz_hint;     /* initial capacity of L / U in entries (0 = 4*nnz(A)+n),    */
     int64_t unz_hint;     /*   cf. SLIP_LU_analysis.lnz/.unz; both grow on demand      */
+    int32_t helpers;      /* helper workgroups (other CUs) that share multi-limb update */
+                          /*   batches of one source: -1 = default (63), 0 = none       */
+    int32_t fork_min;     /* queue length from which a batch is farmed out (0 = default) */
 } slip_hip_options;
 
 typedef struct slip_hip_info {
@@ -112,7 +115,8 @@ void slip_hip_free(void *p);
 /* Wave-level limb kernels (wave_bigint.h) run in isolation on the device, one
  * wavefront per operation, for the parity unit tests.  Operands are arrays of
  * 32-bit digits.  op: 0 = low product a*b mod B^W, 1 = a+b mod B^W,
- * 2 = a-b mod B^W, 3 = inverse of odd a modulo B^W (b unused).
+ * 2 = a-b mod B^W, 3 = inverse of odd a modulo B^W (b unused); 10..13 = the same four
+ * on the register-resident primitives (wave_bigint_reg.h, W <= 256), 14 = a >> lb bits.
  * out receives nops*W digits. */
 int slip_hip_wave_op_test(int32_t op, int32_t nops, int32_t la, int32_t lb, int32_t W,
                           const uint32_t *a, const uint32_t *b, uint32_t *out);

@@ -14,7 +14,8 @@ DEFAULT_SO = os.path.join(_HERE, "csrc", "libslip_hip.so")
 
 class Options(C.Structure):
     _fields_ = [("pivot", C.c_int32), ("tol", C.c_double), ("limb_cap", C.c_int32),
-                ("waves", C.c_int32), ("lnz_hint", C.c_int64), ("unz_hint", C.c_int64)]
+                ("waves", C.c_int32), ("lnz_hint", C.c_int64), ("unz_hint", C.c_int64),
+                ("helpers", C.c_int32), ("fork_min", C.c_int32)]
 
 
 class Info(C.Structure):

@@ -49,7 +49,7 @@ class Factorization:
     """A resident REF LU factorisation on one GPU (handle of slip_hip_factor_*)."""
 
     def __init__(self, n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, limb_cap=0, waves=0,
-                 lnz_hint=0, unz_hint=0, lib_path=None):
+                 lnz_hint=0, unz_hint=0, helpers=-1, fork_min=0, lib_path=None):
         self.lib = _lib.load(lib_path)
         self.n = int(n)
         Ap = np.ascontiguousarray(Ap, dtype=np.int64)
@@ -59,7 +59,7 @@ class Factorization:
         if Alimbs.size == 0:
             Alimbs = np.zeros(1, dtype=np.uint64)
         q = np.ascontiguousarray(q, dtype=np.int32)
-        opt = _lib.Options(pivot, tol, limb_cap, waves, lnz_hint, unz_hint)
+        opt = _lib.Options(pivot, tol, limb_cap, waves, lnz_hint, unz_hint, helpers, fork_min)
         self.h = C.c_void_p()
         rc = self.lib.slip_hip_factor_create(C.byref(self.h), self.n, Ap.ctypes.data, Ai.ctypes.data,
                                              Alen.ctypes.data, Alimbs.ctypes.data, q.ctypes.data,
@@ -124,10 +124,10 @@ class Factorization:
 
 
 def factorize(n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, kmax=0, limb_cap=0, waves=0, check=True,
-              lib_path=None):
+              lib_path=None, helpers=-1, fork_min=0):
     """One-shot SLIP_LU_factorize on the GPU; returns the canonical factor dict."""
     f = Factorization(n, Ap, Ai, Alen, Alimbs, q, pivot=pivot, tol=tol, limb_cap=limb_cap, waves=waves,
-                      lib_path=lib_path)
+                      lib_path=lib_path, helpers=helpers, fork_min=fork_min)
     try:
         rc = f.run(kmax, check=check)
         out = f.download()

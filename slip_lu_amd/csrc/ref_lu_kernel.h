@@ -29,6 +29,7 @@
 #define SLIP_REF_LU_KERNEL_H
 
 #include "wave_bigint.h"
+#include "wave_bigint_reg.h"
 
 typedef unsigned __int128 slip_u128;
 
@@ -39,7 +40,8 @@ enum {
     SLIPDEV_GROW_L = 2,      /* L slab / index arrays full; column status_k not done */
     SLIPDEV_GROW_U = 3,
     SLIPDEV_GROW_X = 4,      /* a value needs more than xcap / wcap / invcap digits  */
-    SLIPDEV_WINDOW_END = 5   /* column status_k holds a value above limb_cap         */
+    SLIPDEV_WINDOW_END = 5,  /* column status_k holds a value above limb_cap         */
+    SLIPDEV_INTERNAL = 6     /* helper workgroups did not answer / inconsistent batch */
 };
 
 /* state of one row of the dense scatter vector x */
@@ -67,11 +69,32 @@ typedef struct SlipParams {
     int64_t *Up; int32_t *Ui; SlipEnt *Ue; uint64_t *Ulimbs; int64_t Ucap_nz, Ucap_nl;
     int32_t *pat;                                   /* pattern of the column: pivot positions, ascending */
     uint32_t *gscratch, *gbitmap;                   /* used when LDS does not hold them */
+    /* helper workgroups (blocks 1..nhelpers): multi-limb updates of one source are farmed out */
+    struct SlipBatch *batch; uint32_t *batch_items;
+    int32_t nhelpers, fork_min;                     /* fork_min: queue length from which a batch is published */
+    int32_t seq0, pad1;                             /* hand-off generation at launch (SlipState.seq)          */
+    int32_t *dbg;                                   /* 4 words per workgroup: hand-off diagnostics            */
 } SlipParams;
+
+/* one published batch of wave-level work (HBM; handed over with agent-scope release/acquire).
+ * The three polled words live in cache lines of their own and are only ever touched with
+ * agent-scope atomics (sc1): a plain store to the same line would leave a private copy in the
+ * writer's XCD L2 that its own polls could then be served from. */
+typedef struct SlipBatch {
+    int32_t seq;  int32_t pad0[31];                 /* generation, bumped by the master to publish   */
+    int32_t done; int32_t pad1[31];                 /* helper workgroups finished with this batch    */
+    int32_t err;  int32_t pad2[31];                 /* first error a helper met (1 grow, 8 internal) */
+    /* payload: plain stores before the release, plain loads after the acquire */
+    int32_t kind, nitems;                           /* 0: leave; 1: IPGE updates (m-m0, i) pairs; 2: history rows */
+    int32_t j, jn, k, stamp;                        /* stamp = the generation this payload belongs to */
+    int64_t m0;
+    int32_t stale_seen, pad4[23];                   /* diagnostics: payload re-reads a helper needed */
+} SlipBatch;
 
 /* mutable across launches */
 typedef struct SlipState {
-    int32_t k_next, status, status_k, pad;
+    int32_t k_next, status, status_k;
+    int32_t seq;                                    /* batch generation: monotonic across launches */
     int64_t Lnz, Lnl, Unz, Unl;
     unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig;
     unsigned long long prof[12];                    /* -DSLIP_PROFILE_PHASES builds only */
@@ -93,7 +116,7 @@ typedef struct SlipState {
 #define SLIP_WORK_CAP      1024
 #define SLIP_LDS_BITMAP    (SLIP_LDS_WORK + 2 * 2 * SLIP_WORK_CAP)
 
-enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_LISTN = 6,
+enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_GEN = 5, SV_LISTN = 6, SV_TMP = 7,
        SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14 };
 
 SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
@@ -216,11 +239,12 @@ SLIP_DEV void slip_store_small(const SlipParams &P, int i, slip_u128 mag, int sg
 /* wave-level pieces                                                    */
 /* ------------------------------------------------------------------ */
 /* make the cached inverse of pivot p's odd part valid modulo B^want (b0,b1,b2: wave scratch) */
-SLIP_DEV int slip_ensure_inv(const SlipParams &P, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2)
+SLIP_DEV int slip_ensure_inv(const SlipParams &P, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2, int publish)
 {
     /* another wave may publish a longer inverse at any time: one lane reads, all agree */
     int have = (int) slip_shfl_u32((uint32_t) *(volatile int32_t *) &P.piv[p].invlen, 0);
     if (have >= want) return 0;
+    if (!publish) return 2;                   /* a helper never writes the shared cache: the master prepared it */
     if (want > P.invcap || want > P.wcap) return 1;
     int target = 2 * have > want ? 2 * have : want;
     if (target > P.invcap) target = P.invcap;
@@ -256,9 +280,143 @@ SLIP_DEV int slip_store_x(const SlipParams &P, int i, const dig_t *q, int W, int
     return 0;
 }
 
+/* ---- register-resident versions (operands of at most 64*D digits; wave_bigint_reg.h) ---- */
+
+/* cached inverse of pivot p's odd part to `want` digits, register Newton; b0: scratch for wide shifts */
+template <int D> SLIP_DEV int slip_ensure_inv_reg(const SlipParams &P, int p, int want, dig_t *b0, int publish)
+{
+    int have = (int) slip_shfl_u32((uint32_t) *(volatile int32_t *) &P.piv[p].invlen, 0);
+    if (have >= want) return 0;
+    if (!publish) return 2;
+    if (want > P.invcap) return 1;
+    int target = 2 * have > want ? 2 * have : want;
+    if (target > P.invcap) target = P.invcap;
+    if (target > 64 * D) target = 64 * D;
+    const SlipPiv pv = P.piv[p];
+    const int ld = slip_abs(pv.len);
+    WR<D> dodd = wr_shr<D>(wr_load<D>(slip_piv_digits(P, pv), ld), pv.ctz, b0);
+    if (ld > 64 * D) {               /* the shift must see the digits above the register window */
+        wb_copy_shr(b0, slip_piv_digits(P, pv), ld, pv.ctz, 64 * D);
+        dodd = wr_load<D>(b0, 64 * D);
+    }
+    dig_t *inv = P.invd + (int64_t) p * P.invcap;
+    WR<D> V = wr_inv_extend<D>(wr_load<D>(inv, have), have, target, dodd);
+    wr_store<D>(inv, V, target);
+    slip_fence_block();
+    if (slip_lane() == 0) slip_atomic_max_i32(&P.piv[p].invlen, target);
+    slip_wave_sync();
+    return 0;
+}
+
+/* store the low W digits of q (normalising, padded to whole limbs) as row i */
+template <int D> SLIP_DEV int slip_store_x_reg(const SlipParams &P, int i, const WR<D> &q, int sign, int h)
+{
+    const int len = wr_len<D>(q);
+    if (len > P.xcap) return 1;
+    dig_t *X = P.xd + (int64_t) i * P.xcap;
+    wr_store<D>(X, q, (len + 1) & ~1);                 /* digits above len are zero in q */
+    if (slip_lane() == 0) {
+        SlipRow r; r.len = sign < 0 ? -len : len; r.h = h; r.pad = 0; r.bits = 0;
+        P.xrow[i] = r;
+    }
+    const uint32_t top = len ? wr_digit<D>(q, len - 1) : 0u;
+    if (slip_lane() == 0) P.xrow[i].bits = len ? 32 * len - slip_clz32(top) : 0;
+    slip_wave_sync();
+    return 0;
+}
+
+template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, int pm, int pd, dig_t *b0, int mode, int publish)
+{
+    const SlipRow xr = P.xrow[r];
+    const int lx = slip_abs(xr.len);
+    const SlipPiv m = P.piv[pm];
+    const int lm = slip_abs(m.len);
+    int sign = slip_sgn(xr.len) * slip_sgn(m.len);
+    if (pd >= 0) {
+        const SlipPiv d = P.piv[pd];
+        const int W = (xr.bits + m.bits - d.bits + 1 + 31) >> 5;
+        { const int e = slip_ensure_inv_reg<D>(P, pd, W, b0, publish); if (e) return e; }
+        if (mode == 1) return 0;
+        WR<D> X = wr_load<D>(P.xd + (int64_t) r * P.xcap, lx), M = wr_load<D>(slip_piv_digits(P, m), lm);
+        WR<D> Y = lx <= lm ? wr_mul<D>(X, lx < 64 * D ? lx : 64 * D, M) : wr_mul<D>(M, lm < 64 * D ? lm : 64 * D, X);
+        Y = wr_mask<D>(wr_shr<D>(Y, d.ctz, b0), W);
+        WR<D> I = wr_load<D>(P.invd + (int64_t) pd * P.invcap, W);
+        Y = wr_mask<D>(wr_mul<D>(I, W, Y), W);
+        return slip_store_x_reg<D>(P, r, Y, sign * slip_sgn(d.len), xr.h);
+    }
+    if (mode == 1) return 0;
+    WR<D> X = wr_load<D>(P.xd + (int64_t) r * P.xcap, lx), M = wr_load<D>(slip_piv_digits(P, m), lm);
+    WR<D> Y = lx <= lm ? wr_mul<D>(X, lx, M) : wr_mul<D>(M, lm, X);
+    return slip_store_x_reg<D>(P, r, Y, sign, xr.h);
+}
+
+template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int j, int jn, int64_t m, dig_t *b0,
+                                                 int W, int W1, int hist, int hdiv, int mode, int publish)
+{
+    const SlipRow xi = P.xrow[i], xj = P.xrow[j];
+    const SlipEnt le = P.Le[m];
+    const SlipPiv R = P.piv[jn];
+    const int has_d = jn >= 1;
+    const int lx = slip_abs(xi.len);
+    SlipPiv Dv = slip_piv_none();
+    if (has_d) Dv = P.piv[jn - 1];
+    if (hdiv) { const int e = slip_ensure_inv_reg<D>(P, xi.h, W1, b0, publish); if (e) return e; }
+    if (has_d) { const int e = slip_ensure_inv_reg<D>(P, jn - 1, W, b0, publish); if (e) return e; }
+    if (mode == 1) return 0;
+    const int CAP = 64 * D;
+    const int lr = slip_abs(R.len) < W1 ? slip_abs(R.len) : W1;
+    WR<D> Rr = wr_load<D>(slip_piv_digits(P, R), lr);
+    /* P1 = hist(x_i) * rho_jn  (mod B^W1), sign s1 */
+    int s1 = slip_sgn(xi.len) * slip_sgn(R.len);
+    WR<D> P1 = wr_zero<D>();
+    if (lx) {
+        const int lxe = lx < CAP ? lx : CAP;
+        WR<D> Y = wr_load<D>(P.xd + (int64_t) i * P.xcap, lxe);
+        int ly = lxe;
+        if (hist) {
+            const int ld = slip_abs(Dv.len) < CAP ? slip_abs(Dv.len) : CAP;
+            WR<D> Dd = wr_load<D>(slip_piv_digits(P, Dv), ld);
+            Y = ly <= ld ? wr_mul<D>(Y, ly, Dd) : wr_mul<D>(Dd, ld, Y);
+            s1 *= slip_sgn(Dv.len);
+            ly = W1;
+            if (hdiv) {
+                const SlipPiv H = P.piv[xi.h];
+                Y = wr_mask<D>(wr_shr<D>(Y, H.ctz, b0), W1);
+                WR<D> IH = wr_load<D>(P.invd + (int64_t) xi.h * P.invcap, W1);
+                Y = wr_mul<D>(IH, W1, Y);
+                s1 *= slip_sgn(H.len);
+            }
+            Y = wr_mask<D>(Y, W1);
+        }
+        P1 = ly <= lr ? wr_mul<D>(Y, ly, Rr) : wr_mul<D>(Rr, lr, Y);
+    }
+    /* P2 = L_m * x_j, sign s2 */
+    const int ll = slip_abs(le.len) < W1 ? slip_abs(le.len) : W1, lj = slip_abs(xj.len) < W1 ? slip_abs(xj.len) : W1;
+    WR<D> Lm = wr_load<D>((const dig_t *)(P.Llimbs + le.off), ll), Xj = wr_load<D>(P.xd + (int64_t) j * P.xcap, lj);
+    WR<D> P2 = ll <= lj ? wr_mul<D>(Lm, ll, Xj) : wr_mul<D>(Xj, lj, Lm);
+    const int s2 = slip_sgn(le.len) * slip_sgn(xj.len);
+    /* T = s1*P1 - s2*P2 (mod B^W1) */
+    int sT;
+    WR<D> T;
+    if (!lx)           { T = wr_addsub<D>(wr_zero<D>(), P2, 1); sT = s2; }
+    else if (s1 == s2) { T = wr_addsub<D>(P1, P2, 1); sT = s1; }
+    else               { T = wr_addsub<D>(P1, P2, 0); sT = s1; }
+    T = wr_mask<D>(T, W1);
+    if (has_d) {
+        T = wr_mask<D>(wr_shr<D>(T, Dv.ctz, b0), W);
+        WR<D> ID = wr_load<D>(P.invd + (int64_t)(jn - 1) * P.invcap, W);
+        T = wr_mask<D>(wr_mul<D>(ID, W, T), W);
+        sT *= slip_sgn(Dv.len);
+    }
+    if (wr_digit<D>(T, W - 1) >> 31) { T = wr_mask<D>(wr_addsub<D>(wr_zero<D>(), T, 1), W); sT = -sT; }
+    return slip_store_x_reg<D>(P, i, T, sT, jn);
+}
+
 /* History update of row r (slip_REF_triangular_solve.c:139-149, 248-257), one wavefront:
  *     x[r] <- x[r] * rho[pm] / rho[pd]      (pd < 0: no division); the history tag is kept */
-SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2)
+/* mode 0: do it; mode 1: only make sure the shared inverse cache covers it.  publish: may extend the cache. */
+SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2,
+                               int mode = 0, int publish = 1)
 {
     const SlipRow xr = P.xrow[r];
     const int lx = slip_abs(xr.len);
@@ -267,9 +425,20 @@ SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t
     const int lm = slip_abs(m.len);
     int sign = slip_sgn(xr.len) * slip_sgn(m.len);
     int bq = xr.bits + m.bits;
+    {
+        /* widths: W digits of result; the shifted product needs W + ceil(ctz/32) */
+        int Wn = (bq + 31) >> 5;
+        if (pd >= 0) { const SlipPiv d0 = P.piv[pd]; Wn = ((bq - d0.bits + 1 + 31) >> 5) + ((d0.ctz + 31) >> 5); }
+        if (Wn > P.wcap) return 1;
+        if (Wn <= 64)  return slip_history_wave_reg<1>(P, r, pm, pd, b0, mode, publish);
+        if (Wn <= 128) return slip_history_wave_reg<2>(P, r, pm, pd, b0, mode, publish);
+        if (Wn <= 192) return slip_history_wave_reg<3>(P, r, pm, pd, b0, mode, publish);
+        if (Wn <= 256) return slip_history_wave_reg<4>(P, r, pm, pd, b0, mode, publish);
+    }
     if (pd < 0) {
         const int W = (bq + 31) >> 5;
         if (W > P.wcap) return 1;
+        if (mode == 1) return 0;
         wb_mul_lo(b0, X, lx, slip_piv_digits(P, m), lm, W);
         return slip_store_x(P, r, b0, W, sign, xr.h);
     }
@@ -277,7 +446,8 @@ SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t
     bq -= d.bits - 1;
     const int W = (bq + 31) >> 5, zh = d.ctz, W2 = W + ((zh + 31) >> 5);
     if (W2 > P.wcap) return 1;
-    if (slip_ensure_inv(P, pd, W, b0, b1, b2)) return 1;
+    { const int e = slip_ensure_inv(P, pd, W, b0, b1, b2, publish); if (e) return e; }
+    if (mode == 1) return 0;
     wb_mul_lo(b0, X, lx, slip_piv_digits(P, m), lm, W2);
     wb_copy_shr(b1, b0, W2, zh, W);
     wb_mul_lo(b2, b1, W, P.invd + (int64_t) pd * P.invcap, W, W);
@@ -287,7 +457,8 @@ SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t
 /* One IPGE update (slip_REF_triangular_solve.c:156-241) of target row i by source row j
  * (pivot position jn) through the L entry m, one wavefront, everything modulo B^W:
  *     x[i] <- ( hist(x[i]) * rho[jn] - L_m * x[j] ) / rho[jn-1]                          */
-SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m, dig_t *b0, dig_t *b1, dig_t *b2)
+SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m, dig_t *b0, dig_t *b1, dig_t *b2,
+                            int mode = 0, int publish = 1)
 {
     const SlipRow xi = P.xrow[i], xj = P.xrow[j];
     const SlipEnt le = P.Le[m];
@@ -318,8 +489,14 @@ SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m
     const int W1 = W + (has_d ? ((zd + 31) >> 5) : 0);
     const int W2 = W1 + (hdiv ? ((zh + 31) >> 5) : 0);
     if (W2 > P.wcap) return 1;
-    if (hdiv && slip_ensure_inv(P, hi, W1, b0, b1, b2)) return 1;
-    if (has_d && slip_ensure_inv(P, jn - 1, W, b0, b1, b2)) return 1;
+    /* operands that fit 256 digits stay in registers */
+    if (W2 <= 64)  return slip_ipge_wave_reg<1>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish);
+    if (W2 <= 128) return slip_ipge_wave_reg<2>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish);
+    if (W2 <= 192) return slip_ipge_wave_reg<3>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish);
+    if (W2 <= 256) return slip_ipge_wave_reg<4>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish);
+    if (hdiv) { const int e = slip_ensure_inv(P, hi, W1, b0, b1, b2, publish); if (e) return e; }
+    if (has_d) { const int e = slip_ensure_inv(P, jn - 1, W, b0, b1, b2, publish); if (e) return e; }
+    if (mode == 1) return 0;
 
     /* P1 = hist(x_i) * rho_jn  -> b1, sign s1 */
     int s1 = sx * sr;
@@ -401,6 +578,160 @@ SLIP_DEV uint64_t slip_top64(const dig_t *X, int l)
     return top;
 }
 
+/* rows[t] (one-limb values, never updated: h < 0) times the long pivot M: the pivot's digits stay in
+ * registers, every wave takes rows in turn (slip_REF_triangular_solve.c:248-257 for untouched rows) */
+template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, const uint32_t *rows, int nrows)
+{
+    const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    const WR<D> Mr = wr_load<D>(Md, slip_abs(M.len));
+    int err = 0;
+    for (int t = wave; t < nrows; t += nw) {
+        const int r = (int) rows[t];
+        const SlipRow xr = P.xrow[r];
+        const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+        WR<D> A = wr_zero<D>();
+        if (lane == 0) A.d[0] = (uint32_t) xv;
+        if (lane == 1) A.d[0] = (uint32_t)(xv >> 32);
+        const WR<D> Y = wr_mul<D>(A, slip_abs(xr.len), Mr);
+        err |= slip_store_x_reg<D>(P, r, Y, slip_sgn(xr.len) * slip_sgn(M.len), xr.h);
+    }
+    return err;
+}
+
+/* ------------------------------------------------------------------ */
+/* wave-level work queues: local drain, or fork over the helper workgroups */
+/* ------------------------------------------------------------------ */
+/* Spins are bounded by ITERATION counts (each iteration sleeps ~1 us): differences of clock64() are
+ * not usable for this -- the counter was observed to jump between two reads of one wave. */
+#define SLIP_SPIN_LIMIT 30000000ull            /* ~30 s: the master gives up on helpers that do not answer   */
+#define SLIP_IDLE_LIMIT 1000000000ull          /* ~15 min: helpers idle for as long as the column loop runs */
+
+SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, int64_t m0, const uint32_t *items, int t,
+                           dig_t *b0, dig_t *b1, dig_t *b2, int mode, int publish)
+{
+    if (kind == 1) return slip_ipge_wave(P, (int) items[2 * t + 1], j, jn, m0 + (int64_t) items[2 * t], b0, b1, b2, mode, publish);
+    const int r = (int) items[t];
+    return slip_history_wave(P, r, k - 1, P.xrow[r].h, b0, b1, b2, mode, publish);
+}
+
+/* Process the nq queued items of list wl (LDS).  Called by all threads right after a workgroup barrier;
+ * returns after a workgroup barrier with every item done and visible.  Errors land in sv[SV_ERR]. */
+SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, int jn, int k, int64_t m0, int nq,
+                         const uint32_t *wl, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    const int fork = P.fork_min > 0 && nq >= P.fork_min;
+    if (!fork) {
+        for (int t = wave; t < nq; t += nw) {
+            const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 1);
+            if (e && lane == 0) sv[SV_ERR] = e;
+        }
+        slip_block_sync();
+        return;
+    }
+    /* 1. the shared inverse cache must cover the batch before other CUs read it */
+    for (int t = wave; t < nq; t += nw) {
+        const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 1, 1);
+        if (e && lane == 0) sv[SV_ERR] = e;
+    }
+    slip_block_sync();
+    if (sv[SV_ERR]) return;
+    /* 2. publish: items and descriptor to HBM, agent-scope release, bump the generation */
+    SlipBatch *B = P.batch;
+    const int nwords = kind == 1 ? 2 * nq : nq;
+    for (int t = tid; t < nwords; t += T) P.batch_items[t] = wl[t];
+    if (tid == 0) {
+        B->kind = kind; B->nitems = nq; B->j = j; B->jn = jn; B->k = k; B->m0 = m0; B->stamp = sv[SV_GEN] + 1;
+        slip_agent_store_i32(&B->err, 0); slip_agent_store_i32(&B->done, 0);
+    }
+    slip_vm_drain();
+    slip_block_sync();
+    const int H = P.nhelpers;
+    if (tid == 0 && H > 0) {
+        slip_agent_release();
+        const int g = sv[SV_GEN] + 1;
+        sv[SV_GEN] = g;
+        slip_agent_store_i32(&B->seq, g);
+    }
+    /* 3. this workgroup's share (global wave index = wave, stride over all waves of all workgroups) */
+    for (int t = wave; t < nq; t += nw * (H + 1)) {
+        const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 0);
+        if (e && lane == 0) sv[SV_ERR] = e == 2 ? 7 : e;
+    }
+    /* 4. wait for the helpers, then acquire what they wrote */
+    slip_vm_drain();
+    slip_block_sync();
+    if (H > 0) {
+        if (tid == 0) {
+            unsigned long long spins = 0;
+            int ok = 1;
+            while (slip_agent_load_i32(&B->done) < H) {
+                slip_sleep();
+                if (++spins > SLIP_SPIN_LIMIT) { ok = 0; break; }
+            }
+            slip_agent_acquire();
+            const int he = slip_agent_load_i32(&B->err);
+            if (!ok) { sv[SV_ERR] = 6; P.dbg[0] = sv[SV_GEN]; P.dbg[1] = slip_agent_load_i32(&B->done); P.dbg[2] = kind; P.dbg[3] = nq; }
+            else if (he && sv[SV_ERR] < 6) sv[SV_ERR] = he;
+        }
+        slip_block_sync();
+    }
+}
+
+/* helper workgroups: wait for batches, do their share, report */
+SLIP_DEV void slip_helper_loop(const SlipParams &P, const SlipState *st, uint32_t *lds, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    const int tid = slip_tid(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    SlipBatch *B = P.batch;
+    const int H = P.nhelpers;
+    int seen = P.seq0;                       /* the generation the previous launch ended with */
+    (void) st;
+    for (;;) {
+        if (tid == 0) {
+            unsigned long long spins = 0;
+            int s, gave_up = 0;
+            P.dbg[4 * slip_block() + 1] = 1;                 /* polling for a generation newer than `seen` */
+            /* only a NEWER generation is a batch (an old value could be a stale copy of the word) */
+            while ((int32_t)((s = slip_agent_load_i32(&B->seq)) - seen) <= 0) {
+                slip_sleep();
+                if (++spins > SLIP_IDLE_LIMIT) { gave_up = 1; break; }
+            }
+            slip_agent_acquire();
+            /* the payload must carry the same generation; if not, this CU still sees old lines: acquire again */
+            while (!gave_up && *(volatile int32_t *) &B->stamp != s) {
+                slip_agent_add_i32(&B->stale_seen, 1);
+                slip_sleep();
+                slip_agent_acquire();
+                if (++spins > SLIP_IDLE_LIMIT) gave_up = 1;
+            }
+            sv[SV_GEN] = s; sv[SV_ERR] = 0; sv[SV_TMP] = gave_up;
+        }
+        slip_block_sync();
+        const int s = sv[SV_GEN];
+        if (sv[SV_TMP]) { if (tid == 0) P.dbg[4 * slip_block() + 1] = 5; return; }   /* idle limit: nobody talks to us */
+        seen = s;
+        const int kind = B->kind, nitems = B->nitems, j = B->j, jn = B->jn, k = B->k;
+        if (tid == 0) { P.dbg[4 * slip_block()] = s; P.dbg[4 * slip_block() + 1] = 2; P.dbg[4 * slip_block() + 2] = kind; P.dbg[4 * slip_block() + 3] = nitems; }
+        if (kind == 0) { if (tid == 0) P.dbg[4 * slip_block() + 1] = 4; return; }     /* the column loop has ended */
+        const int64_t m0 = B->m0;
+        for (int t = slip_block() * nw + wave; t < nitems; t += nw * (H + 1)) {
+            const int e = slip_run_item(P, kind, j, jn, k, m0, P.batch_items, t, b0, b1, b2, 0, 0);
+            if (e && lane == 0) sv[SV_ERR] = e == 2 ? 8 : 1;      /* 1: a buffer is too small (the host grows it) */
+        }
+        slip_vm_drain();
+        slip_block_sync();
+        if (tid == 0) {
+            if (sv[SV_ERR]) slip_agent_store_i32(&B->err, sv[SV_ERR]);
+            slip_agent_release();
+            slip_agent_add_i32(&B->done, 1);
+            P.dbg[4 * slip_block() + 1] = 3;
+        }
+        slip_block_sync();
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* one column; returns a SLIPDEV_* status (0 = committed)              */
 /* ------------------------------------------------------------------ */
@@ -466,14 +797,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             if (tid == 0) sv[SV_CNT0 + (step + 1) % 3] = 0;
             if (nq > 0) {
                 slip_block_sync();
-                const uint32_t *wlp = work + ((step + 1) & 1) * 2 * SLIP_WORK_CAP;
-                const int64_t pm0 = P.Lp[pjn];
-                for (int t = wave; t < nq; t += nw) {
-                    const int64_t m = pm0 + (int64_t) wlp[2 * t];
-                    const int i = (int) wlp[2 * t + 1];
-                    if (slip_ipge_wave(P, i, pj, pjn, m, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
-                }
-                slip_block_sync();
+                slip_drain(P, lds, 1, pj, pjn, k, P.Lp[pjn], nq, work + ((step + 1) & 1) * 2 * SLIP_WORK_CAP, b0, b1, b2);
+                if (sv[SV_ERR]) break;
             }
             const int jn = slip_bitmap_next(bm, cur + 1, k);
             if (jn < 0) break;
@@ -522,11 +847,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                         slip_block_sync();
                     }
                     const int nq2 = *wcnt;
-                    for (int t = wave; t < nq2; t += nw) {
-                        const int64_t m = m0 + (int64_t) wl[2 * t];
-                        if (slip_ipge_wave(P, (int) wl[2 * t + 1], j, jn, m, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
-                    }
-                    slip_block_sync();
+                    slip_drain(P, lds, 1, j, jn, k, m0, nq2, wl, b0, b1, b2);
                     if (tid == 0) *wcnt = 0;
                     slip_block_sync();
                 }
@@ -584,7 +905,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         }
     }
     slip_block_sync();
-    if (sv[SV_ERR]) return SLIPDEV_GROW_X;
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
     SLIP_STAMP(1);
 
     /* ---- phase 3: read the bitmap in order = the sorted pattern (slip_sort_xi.c) ---- */
@@ -617,8 +938,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
 
     /* ---- phase 4: history update of the non-pivotal rows to level k-1 (:248-257) ---- */
     if (k >= 1) {
-        volatile int32_t *wcnt = &sv[SV_CNT0];
-        if (tid == 0) *wcnt = 0;
+        volatile int32_t *wcnt = &sv[SV_CNT0], *wcnt2 = &sv[SV_CNT0 + 1];
+        if (tid == 0) { *wcnt = 0; *wcnt2 = 0; }
+        uint32_t *wl2 = work + 2 * SLIP_WORK_CAP;
         /* rho[k-1] is the multiplier of every row: stage its digits once (LDS when it fits) */
         const SlipPiv M = P.piv[k - 1];
         const int lm = slip_abs(M.len);
@@ -642,8 +964,13 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                     if (slip_history_small(P, xr, xv, k - 1, xr.h, &y, &ys)) {
                         slip_store_small(P, r, y, ys, xr.h);
                         done = 1;
+                    } else if (xr.h < 0 && lm + 2 <= P.xcap && lm + 2 <= 256) {
+                        /* one limb times a long pivot, no division: wave path with the pivot in registers */
+                        const int at = slip_atomic_add_i32((int32_t *) wcnt2, 1);
+                        wl2[at] = (uint32_t) r;
+                        done = 1;
                     } else if (xr.h < 0 && lm + 2 <= P.xcap) {
-                        /* one limb times a long pivot, no division: this lane walks the pivot's digits */
+                        /* beyond 256 digits: this lane walks the pivot's digits */
                         dig_t *X = P.xd + (int64_t) r * P.xcap;
                         const uint64_t a0 = xv & 0xFFFFFFFFu, a1 = xv >> 32;
                         uint64_t carry = 0;              /* < 2^64 */
@@ -666,22 +993,29 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             }
             slip_block_sync();
             SLIP_STAMP(9);
+            {
+                const int n2 = *wcnt2;
+                if (n2 > 0) {
+                    const int Dm = (lm + 2 + 63) >> 6;
+                    int e;
+                    if (Dm <= 1) e = slip_mul_rows_reg<1>(P, M, Md, wl2, n2);
+                    else if (Dm == 2) e = slip_mul_rows_reg<2>(P, M, Md, wl2, n2);
+                    else if (Dm == 3) e = slip_mul_rows_reg<3>(P, M, Md, wl2, n2);
+                    else e = slip_mul_rows_reg<4>(P, M, Md, wl2, n2);
+                    if (e && lane == 0) sv[SV_ERR] = 1;
+                }
+            }
             const int nq = *wcnt;
 #ifdef SLIP_PROFILING
             if (tid == 0) st->prof[11] += (unsigned long long) nq;
 #endif
-            for (int t = wave; t < nq; t += nw) {
-                const int r = (int) wl[t];
-                const int hr = P.xrow[r].h;
-                if (slip_history_wave(P, r, k - 1, hr, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
-            }
-            slip_block_sync();
+            slip_drain(P, lds, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
             SLIP_STAMP(10);
-            if (tid == 0) *wcnt = 0;
+            if (tid == 0) { *wcnt = 0; *wcnt2 = 0; }
             slip_block_sync();
         }
     }
-    if (sv[SV_ERR]) return SLIPDEV_GROW_X;
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
     SLIP_STAMP(3);
 
     /* ---- phase 5: column-window cap, then the pivot search ---- */
@@ -840,7 +1174,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         const int r = isU ? P.Ui[at] : P.Li[at];
         const SlipEnt en = isU ? P.Ue[at] : P.Le[at];
         dig_t *dst = isU ? (dig_t *)(P.Ulimbs + en.off) : (dig_t *)(P.Llimbs + en.off);
-        wb_copy_pad(dst, P.xd + (int64_t) r * P.xcap, slip_abs(en.len));
+        /* x rows are stored padded to whole limbs; nobody reads the slab before the barrier below */
+        const dig_t *srcx = P.xd + (int64_t) r * P.xcap;
+        const int lw = (slip_abs(en.len) + 1) & ~1;
+        for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = srcx[c];
     }
     slip_block_sync();
     SLIP_STAMP(6);
@@ -885,8 +1222,17 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
 template <bool BM_LDS, bool SCR_LDS>
 SLIP_DEV void slip_factor_columns(const SlipParams &P, SlipState *st, uint32_t *lds)
 {
+    if (slip_block() != 0) {
+        const int wcap = P.wcap, wave = slip_wave();
+        dig_t *hb0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
+                             : P.gscratch + ((int64_t) slip_block() * slip_nwaves() + wave) * 3 * wcap;
+        slip_helper_loop(P, st, lds, hb0, hb0 + wcap, hb0 + 2 * wcap);
+        return;
+    }
     unsigned long long t_read = 0, t_upd = 0, t_src = 0, t_str = 0;
     volatile int64_t *sv64 = (volatile int64_t *)(lds + SLIP_LDS_VARS);
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    if (slip_tid() == 0) sv[SV_GEN] = P.seq0;
     int k = st->k_next;
     if (slip_tid() == 0) {
         sv64[SV_LNZ / 2] = st->Lnz; sv64[SV_LNL / 2] = st->Lnl; sv64[SV_UNZ / 2] = st->Unz; sv64[SV_UNL / 2] = st->Unl;
@@ -898,6 +1244,13 @@ SLIP_DEV void slip_factor_columns(const SlipParams &P, SlipState *st, uint32_t *
         if (status != SLIPDEV_OK) break;
     }
     slip_block_sync();
+    /* release the helper workgroups */
+    if (P.nhelpers > 0 && slip_tid() == 0) {
+        P.batch->kind = 0; P.batch->stamp = sv[SV_GEN] + 1;
+        slip_agent_release();
+        sv[SV_GEN] = sv[SV_GEN] + 1;
+        slip_agent_store_i32(&P.batch->seq, sv[SV_GEN]);
+    }
     /* per-thread counters -> totals */
     uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
     uint64_t e0, e1, a, b, c, d;
@@ -906,7 +1259,7 @@ SLIP_DEV void slip_factor_columns(const SlipParams &P, SlipState *st, uint32_t *
     if (slip_tid() == 0) {
         st->c_read += a; st->c_upd += b; st->c_src += c; st->c_streamed += d;
         st->Lnz = sv64[SV_LNZ / 2]; st->Lnl = sv64[SV_LNL / 2]; st->Unz = sv64[SV_UNZ / 2]; st->Unl = sv64[SV_UNL / 2];
-        st->k_next = k; st->status = status; st->status_k = k;
+        st->k_next = k; st->status = status; st->status_k = k; st->seq = sv[SV_GEN];
     }
 }
 

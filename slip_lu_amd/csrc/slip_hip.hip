@@ -12,6 +12,7 @@
  * never the product.
  */
 #include "ref_lu_kernel.h"
+#include "wave_bigint_reg.h"
 #include "slip_matgen.h"
 #include "../../include/slip_hip.h"
 
@@ -30,6 +31,42 @@
 /* ------------------------------------------------------------------ */
 /* kernels                                                             */
 /* ------------------------------------------------------------------ */
+/* register-resident primitives (wave_bigint_reg.h) for the unit tests: op 10 product, 11 add, 12 sub,
+ * 13 inverse of odd a, 14 a >> lb (lb = shift in bits); all modulo B^W, W <= 256 */
+template <int D> SLIP_DEV void slip_reg_op_test_d(int op, const uint32_t *A, int la, const uint32_t *B, int lb, int W,
+                                                   uint32_t *O, uint32_t *scratch)
+{
+    WR<D> a = wr_load<D>(A, la < W ? la : W), r;
+    if (op == 14) r = wr_shr<D>(a, lb, scratch);
+    else if (op == 13) r = wr_inv_extend<D>(wr_zero<D>(), 0, W, a);
+    else {
+        WR<D> b = wr_load<D>(B, lb < W ? lb : W);
+        const int ea = la < W ? la : W, eb = lb < W ? lb : W;
+        if (op == 10) r = ea <= eb ? wr_mul<D>(a, ea, b) : wr_mul<D>(b, eb, a);
+        else r = wr_addsub<D>(a, b, op == 12);
+    }
+    wr_store<D>(O, r, W);
+}
+SLIP_DEV void slip_reg_op_test(int op, const uint32_t *A, int la, const uint32_t *B, int lb, int W, uint32_t *O, uint32_t *scratch)
+{
+    if (op >= 20) {                                   /* raw cross-lane primitives: W must be 64 */
+        const int lane = slip_lane();
+        const uint32_t v = A[lane];
+        uint32_t r = 0;
+        if (op == 20) r = slip_dpp_shr1(v, 0xAAAAu);
+        else if (op == 21) r = slip_dpp_shl1(v, 0xBBBBu);
+        else if (op == 22) r = slip_readlane(v, lb);
+        else if (op == 23) r = slip_shfl_up_u32(v, 1);
+        O[lane] = r;
+        return;
+    }
+    const int D = (W + 63) >> 6;
+    if (D <= 1) slip_reg_op_test_d<1>(op, A, la, B, lb, W, O, scratch);
+    else if (D == 2) slip_reg_op_test_d<2>(op, A, la, B, lb, W, O, scratch);
+    else if (D == 3) slip_reg_op_test_d<3>(op, A, la, B, lb, W, O, scratch);
+    else slip_reg_op_test_d<4>(op, A, la, B, lb, W, O, scratch);
+}
+
 #ifndef SLIP_EMULATE
 #define SLIP_MAX_WAVES 8                   /* 512 threads: 2 waves per SIMD, 256 VGPRs per lane */
 template <bool BM_LDS, bool SCR_LDS>
@@ -37,7 +74,7 @@ __global__ void __launch_bounds__(64 * SLIP_MAX_WAVES)
 slip_factor_kernel(SlipParams P, SlipState *st)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t slip_lds[];
-    slip_factor_columns<BM_LDS, SCR_LDS>(P, st, slip_lds);
+    slip_factor_columns<BM_LDS, SCR_LDS>(P, st, slip_lds);      /* block 0: column loop; blocks >= 1: helpers */
 }
 
 /* unit-test kernel: block b performs operation b with one wavefront */
@@ -51,7 +88,8 @@ slip_wave_op_kernel(int op, int la, int lb, int W, const uint32_t *a, const uint
     if (op == 0) wb_mul_lo(O, A, la, B, lb, W);
     else if (op == 1) wb_addsub(O, A, la, B, lb, W, 0);
     else if (op == 2) wb_addsub(O, A, la, B, lb, W, 1);
-    else wb_inv_extend(O, 0, W, A, la, s0, s1);
+    else if (op == 3) wb_inv_extend(O, 0, W, A, la, s0, s1);
+    else slip_reg_op_test(op, A, la, B, lb, W, O, s0);
 }
 
 /* micro-benchmark kernel (development aid): cycles per wave-level primitive, nwaves waves busy */
@@ -73,6 +111,13 @@ slip_wave_bench_kernel(int op, int la, int lb, int W, int iters, int out_in_lds,
         else if (op == 3) wb_copy_shr(O, B, lb, 3, W);
         else if (op == 4) { wb_mul_lo(O, A, la, B, lb, W); wb_mul_lo(O2, O, W, A, la, W); }
         else if (op == 5) slip_wave_sync();
+        else if (op == 6) {                    /* register product, operands already loaded */
+            const int ea = la < W ? la : W;
+            if (W <= 64) { WR<1> x = wr_load<1>(A, ea), y = wr_load<1>(B, lb < W ? lb : W); wr_store<1>(O, wr_mul<1>(x, ea, y), W); }
+            else if (W <= 128) { WR<2> x = wr_load<2>(A, ea), y = wr_load<2>(B, lb < W ? lb : W); wr_store<2>(O, wr_mul<2>(x, ea, y), W); }
+            else if (W <= 192) { WR<3> x = wr_load<3>(A, ea), y = wr_load<3>(B, lb < W ? lb : W); wr_store<3>(O, wr_mul<3>(x, ea, y), W); }
+            else { WR<4> x = wr_load<4>(A, ea), y = wr_load<4>(B, lb < W ? lb : W); wr_store<4>(O, wr_mul<4>(x, ea, y), W); }
+        }
     }
     unsigned long long t1 = clock64();
     if (slip_lane() == 0) cycles[wave] = (t1 - t0) / (unsigned long long) iters;
@@ -124,6 +169,7 @@ extern "C" void slip_hip_default_options(slip_hip_options *o)
 {
     /* SLIP_LU_internal.h:136-149: pivot = SLIP_TOL_SMALLEST, tol = 1 */
     o->pivot = 3; o->tol = 1.0; o->limb_cap = 0; o->waves = 0; o->lnz_hint = 0; o->unz_hint = 0;
+    o->helpers = -1; o->fork_min = 0;
 }
 
 extern "C" int slip_hip_device_count(void)
@@ -171,7 +217,7 @@ static int alloc_x(slip_hip_factor *f, int32_t xcap)
     /* cached inverses are gone: pivots recompute them on demand (invlen = 0) */
     if (hipMemset(P->piv, 0, (size_t) P->n * sizeof(SlipPiv)) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
     plan_launch(f);
-    if (dev_alloc(&P->gscratch, (int64_t) 16 * 3 * P->wcap)) return SLIP_HIP_OUT_OF_MEMORY;
+    if (dev_alloc(&P->gscratch, (int64_t)(P->nhelpers + 1) * 16 * 3 * P->wcap)) return SLIP_HIP_OUT_OF_MEMORY;
     return 0;
 }
 
@@ -188,7 +234,11 @@ extern "C" int slip_hip_factor_reset(slip_hip_factor *f)
     free(id);
     CK(hipMemset(P->Lp, 0, 8));
     CK(hipMemset(P->Up, 0, 8));
-    memset(&f->hs, 0, sizeof f->hs);
+    {
+        const int32_t seq = f->hs.seq;                 /* the hand-off generation never goes back */
+        memset(&f->hs, 0, sizeof f->hs);
+        f->hs.seq = seq;
+    }
     CK(hipMemcpy(f->ds, &f->hs, sizeof(SlipState), hipMemcpyHostToDevice));
     f->last_status = 0; f->window_end = 0; f->kernel_ms = 0; f->launches = 0;
     return SLIP_HIP_OK;
@@ -203,7 +253,7 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
     hipFree(P->piv); hipFree(P->invd);
     hipFree(P->Lp); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
     hipFree(P->Up); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
-    hipFree(P->pat); hipFree(P->gscratch); hipFree(P->gbitmap);
+    hipFree(P->pat); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->batch); hipFree(P->batch_items); hipFree(P->dbg);
     hipFree(f->ds);
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
@@ -281,6 +331,12 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     SlipParams *P = &f->P;
     f->n = n; f->annz = onz; f->alimbs = ol;
     f->waves = opt.waves > 0 ? opt.waves : 8;
+    /* helper workgroups for multi-limb batches: default 63 (64 of the 256 CUs), 0 disables */
+    P->nhelpers = opt.helpers < 0 ? 63 : (opt.helpers > 255 ? 255 : opt.helpers);
+    P->fork_min = opt.fork_min > 0 ? opt.fork_min : (P->nhelpers > 0 ? 24 : 0);
+#ifdef SLIP_EMULATE
+    P->nhelpers = 0;                                   /* the emulator runs one workgroup at a time */
+#endif
 #ifndef SLIP_MAX_WAVES
 #define SLIP_MAX_WAVES 16                  /* emulation build */
 #endif
@@ -298,6 +354,9 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n)); A_(dev_alloc(&P->xrow, n));
     A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->pat, n));
     A_(dev_alloc(&P->gbitmap, (int64_t)(n + 31) / 32 + 64));
+    A_(dev_alloc(&P->batch, 1)); A_(dev_alloc(&P->batch_items, 2 * 2 * SLIP_WORK_CAP)); A_(dev_alloc(&P->dbg, 4 * 256));
+    if (!rc && hipMemset(P->dbg, 0, 4 * 256 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->batch, 0, sizeof(SlipBatch)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     /* initial sizes: S->lnz/unz only size the first allocation in the reference too */
     P->Lcap_nz = opt.lnz_hint > 0 ? opt.lnz_hint : 4 * onz + n;
     P->Ucap_nz = opt.unz_hint > 0 ? opt.unz_hint : 4 * onz + n;
@@ -335,10 +394,11 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
 
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
+    f->P.seq0 = f->hs.seq;
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;
-    const dim3 grid(1), block(64 * f->waves);
+    const dim3 grid(1 + f->P.nhelpers), block(64 * f->waves);
 #define SLIP_LAUNCH(BM, SC) do { \
         CK(hipFuncSetAttribute((const void *) slip_factor_kernel<BM, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes)); \
         hipLaunchKernelGGL((slip_factor_kernel<BM, SC>), grid, block, lds_bytes, stream, f->P, f->ds); } while (0)
@@ -412,7 +472,22 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
             }
             free(keep);
             if (e) { rc = e; break; }
-        } else { rc = SLIP_HIP_DEVICE_ERROR; break; }
+        } else {
+            fprintf(stderr, "slip_hip: kernel stopped with internal status %d at column %d\n", h->status, h->status_k);
+            {   /* hand-off diagnostics: who did not answer */
+                int32_t dbg[4 * 256];
+                if (hipMemcpy(dbg, P->dbg, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
+                    fprintf(stderr, "  master: gen %d, done %d of %d, kind %d, items %d\n", dbg[0], dbg[1], P->nhelpers, dbg[2], dbg[3]);
+                    for (int b = 1; b <= P->nhelpers; b++)
+                        if (!(dbg[4 * b] == dbg[0] + 1 && dbg[4 * b + 1] == 4))
+                            fprintf(stderr, "  helper %d: gen %d stage %d kind %d items %d\n", b, dbg[4 * b], dbg[4 * b + 1], dbg[4 * b + 2], dbg[4 * b + 3]);
+                    SlipBatch hb;
+                    if (hipMemcpy(&hb, P->batch, sizeof hb, hipMemcpyDeviceToHost) == hipSuccess)
+                        fprintf(stderr, "  batch: seq %d done %d err %d kind %d stamp %d stale_seen %d\n", hb.seq, hb.done, hb.err, hb.kind, hb.stamp, hb.stale_seen);
+                }
+            }
+            rc = SLIP_HIP_DEVICE_ERROR; break;
+        }
     }
     f->last_status = rc;
     return rc;
@@ -501,14 +576,15 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
 extern "C" int slip_hip_wave_op_test(int32_t op, int32_t nops, int32_t la, int32_t lb, int32_t W,
                                      const uint32_t *a, const uint32_t *b, uint32_t *out)
 {
-    if (nops <= 0 || la <= 0 || W <= 0 || !a || !out || (op != 3 && (!b || lb <= 0))) return SLIP_HIP_INCORRECT_INPUT;
+    if (nops <= 0 || la <= 0 || W <= 0 || !a || !out || (op != 3 && op != 13 && op != 14 && (!b || lb <= 0))) return SLIP_HIP_INCORRECT_INPUT;
+    if (op >= 10 && W > 256) return SLIP_HIP_INCORRECT_INPUT;
     if (slip_hip_device_count() <= 0) return SLIP_HIP_DEVICE_ERROR;
     uint32_t *da = NULL, *db = NULL, *dout = NULL, *ds = NULL;
-    const int64_t lbb = lb > 0 ? lb : 1;
+    const int64_t lbb = (lb > 0 && op != 14) ? lb : 1;
     if (dev_alloc(&da, (int64_t) nops * la) || dev_alloc(&db, (int64_t) nops * lbb) ||
         dev_alloc(&dout, (int64_t) nops * W) || dev_alloc(&ds, (int64_t) nops * 2 * (W + 1))) return SLIP_HIP_OUT_OF_MEMORY;
     CK(hipMemcpy(da, a, (size_t) nops * la * 4, hipMemcpyHostToDevice));
-    if (b && lb > 0) CK(hipMemcpy(db, b, (size_t) nops * lb * 4, hipMemcpyHostToDevice));
+    if (b && lb > 0 && op != 14) CK(hipMemcpy(db, b, (size_t) nops * lb * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dout, 0, (size_t) nops * W * 4));
 #ifndef SLIP_EMULATE
     hipLaunchKernelGGL(slip_wave_op_kernel, dim3(nops), dim3(64), 0, 0, op, la, lb, W, da, db, dout, ds);
@@ -521,7 +597,8 @@ extern "C" int slip_hip_wave_op_test(int32_t op, int32_t nops, int32_t la, int32
         if (op == 0) wb_mul_lo(O, A, la, B, lb, W);
         else if (op == 1) wb_addsub(O, A, la, B, lb, W, 0);
         else if (op == 2) wb_addsub(O, A, la, B, lb, W, 1);
-        else wb_inv_extend(O, 0, W, A, la, s0, s1);
+        else if (op == 3) wb_inv_extend(O, 0, W, A, la, s0, s1);
+        else slip_reg_op_test(op, A, la, B, lb, W, O, s0);
     });
 #endif
     CK(hipDeviceSynchronize());

@@ -33,12 +33,27 @@ static inline int slip_nblocks(void)  { return emu::nblocks(); }
 #define slip_ballot(pred)      emu::ballot((pred), __LINE__)
 #define slip_shfl_u32(v, src)  ((uint32_t) emu::shfl((uint64_t)(v), (src), __LINE__))
 #define slip_shfl_u64(v, src)  emu::shfl((uint64_t)(v), (src), __LINE__)
+/* lane l receives lane l-1's value (lane 0: fill) / lane l+1's (lane 63: fill) / rotation; uniform-lane read */
+static inline uint32_t slip_emu_shr1(const uint64_t *o, uint32_t fill) { int l = emu::tid() & 63; return l ? (uint32_t) o[l - 1] : fill; }
+static inline uint32_t slip_emu_shl1(const uint64_t *o, uint32_t fill) { int l = emu::tid() & 63; return l < 63 ? (uint32_t) o[l + 1] : fill; }
+#define slip_dpp_shr1(v, fill) slip_emu_shr1(emu::collective((uint64_t)(v), __LINE__), (fill))
+#define slip_dpp_shl1(v, fill) slip_emu_shl1(emu::collective((uint64_t)(v), __LINE__), (fill))
+#define slip_readlane(v, lane) ((uint32_t) emu::shfl((uint64_t)(v), (lane), __LINE__))
 static inline uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 static inline int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v > o) *p = v; return o; }
 static inline int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
 static inline unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline void slip_fence_block(void) {}
 static inline void slip_fence_device(void) {}
+/* agent-scope hand-off primitives (no-ops on the sequential emulator) */
+static inline void slip_vm_drain(void) {}
+static inline void slip_agent_release(void) {}
+static inline void slip_agent_acquire(void) {}
+static inline int32_t slip_agent_load_i32(const int32_t *p) { return *(volatile const int32_t *) p; }
+static inline void slip_agent_store_i32(int32_t *p, int32_t v) { *(volatile int32_t *) p = v; }
+static inline int32_t slip_agent_add_i32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
+static inline void slip_sleep(void) {}
+static inline unsigned long long slip_clock(void) { return 0; }
 static inline int slip_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 static inline int slip_ctz32(uint32_t v) { return v ? __builtin_ctz(v) : 32; }
 static inline int slip_clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
@@ -73,12 +88,44 @@ SLIP_DEV uint64_t slip_shfl_u64(uint64_t v, int src)
     uint32_t hi = (uint32_t) __shfl((int)(uint32_t)(v >> 32), src, SLIP_WAVE);
     return ((uint64_t) hi << 32) | lo;
 }
+/* DPP wave shifts (GFX9 wave_shr:1 / wave_shl:1): one VALU op, no LDS crossbar */
+SLIP_DEV uint32_t slip_dpp_shr1(uint32_t v, uint32_t fill)
+{
+    return (uint32_t) __builtin_amdgcn_update_dpp((int) fill, (int) v, 0x138, 0xF, 0xF, false);
+}
+SLIP_DEV uint32_t slip_dpp_shl1(uint32_t v, uint32_t fill)
+{
+    return (uint32_t) __builtin_amdgcn_update_dpp((int) fill, (int) v, 0x130, 0xF, 0xF, false);
+}
+SLIP_DEV uint32_t slip_readlane(uint32_t v, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) v, lane); }
 SLIP_DEV uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 SLIP_DEV int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { return atomicMax(p, v); }
 SLIP_DEV int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { return atomicAdd(p, v); }
 SLIP_DEV unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 SLIP_DEV void slip_fence_block(void) { __threadfence_block(); }
 SLIP_DEV void slip_fence_device(void) { __threadfence(); }
+/* agent-scope hand-off between workgroups on different CUs / XCDs (cdna_hip_programming.md, Guideline 16):
+ * producer: stores -> every storing wave drains (vmcnt(0)) -> workgroup barrier -> ONE lane release
+ *           -> drain -> relaxed agent-scope flag store / counter add;
+ * consumer: ONE lane polls relaxed -> agent acquire -> drain -> workgroup barrier -> plain loads. */
+SLIP_DEV void slip_vm_drain(void) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+SLIP_DEV void slip_agent_release(void)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+SLIP_DEV void slip_agent_acquire(void)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+/* polled words are read with a returning agent-scope RMW (add 0): it is performed at the memory side, so it
+ * cannot be served from a stale copy of the line in this XCD's L2 (observed: rare polls that never saw an update) */
+SLIP_DEV int32_t slip_agent_load_i32(const int32_t *p) { return __hip_atomic_fetch_add((int32_t *) p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV void slip_agent_store_i32(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV int32_t slip_agent_add_i32(int32_t *p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV void slip_sleep(void) { __builtin_amdgcn_s_sleep(32); }
+SLIP_DEV unsigned long long slip_clock(void) { return (unsigned long long) clock64(); }
 SLIP_DEV int slip_clz32(uint32_t v) { return __clz((int) v); }
 SLIP_DEV int slip_ctz32(uint32_t v) { return v ? __ffs((int) v) - 1 : 32; }
 SLIP_DEV int slip_clz64(uint64_t v) { return __clzll((long long) v); }

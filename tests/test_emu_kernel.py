@@ -19,13 +19,13 @@ def emu_lib():
     return EMU
 
 
-@pytest.mark.parametrize("name,waves", [("test_mat", 2), ("test_mat_p1", 1), ("test_mat_p2", 4), ("test_mat_p4tol", 2),
-                                        ("test_mat_p5", 2), ("test_mat_tol01", 2), ("test_mat_noord", 16),
-                                        ("gen_n40", 2)])
-def test_emulated_kernel_matches_reference(emu_lib, name, waves):
+@pytest.mark.parametrize("name,waves,fork_min", [("test_mat", 2, 0), ("test_mat_p1", 1, 0), ("test_mat_p2", 4, 0),
+                                                 ("test_mat_p4tol", 2, 0), ("test_mat_p5", 2, 1), ("test_mat_tol01", 2, 0),
+                                                 ("test_mat_noord", 16, 0), ("gen_n40", 2, 0), ("gen_n40", 4, 1)])
+def test_emulated_kernel_matches_reference(emu_lib, name, waves, fork_min):
     import slip_lu_amd as sl
     entry, fix = load_case(name)
     res = sl.factorize(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"],
                        pivot=entry["pivot"], tol=entry["tol"], kmax=entry["kmax"], limb_cap=entry["cap"],
-                       waves=waves, lib_path=emu_lib)
+                       waves=waves, fork_min=fork_min, lib_path=emu_lib)   # fork_min: batch hand-off path, no helpers
     check_against_golden(entry, fix, res)

@@ -124,27 +124,30 @@ def _digits(v, n):
     return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
 
 
-@pytest.mark.parametrize("op", [0, 1, 2, 3])
+@pytest.mark.parametrize("op", [0, 1, 2, 3, 10, 11, 12, 13])
 def test_gpu_wave_limb_ops(op):
-    """wave_bigint.h primitives on the device vs Python integers."""
+    """wave_bigint.h / wave_bigint_reg.h primitives on the device vs Python integers."""
     import ctypes as C
     from slip_lu_amd import _lib
     lib = _lib.load()
     rnd = random.Random(100 + op)
-    for la, lb, W in [(1, 1, 2), (2, 5, 7), (64, 64, 128), (65, 3, 66), (130, 129, 200), (100, 128, 64), (7, 200, 207)]:
+    for la, lb, W in [(1, 1, 2), (2, 5, 7), (64, 64, 128), (65, 3, 66), (130, 129, 200), (100, 128, 64), (7, 200, 207),
+                      (128, 128, 256), (200, 256, 256)]:
+        if op >= 10 and W > 256:
+            continue
         nops = 24
         A, B, exp = [], [], []
         for t in range(nops):
             kind = t % 4
             a = rnd.getrandbits(32 * la) if kind else (1 << (32 * la)) - 1
             b = rnd.getrandbits(32 * lb) if kind != 1 else (1 << (32 * lb)) - 1
-            if op == 3:
+            if op % 10 == 3:
                 a |= 1
             A += _digits(a, la); B += _digits(b, lb)
             m = 1 << (32 * W)
-            if op == 0: e = (a * b) % m
-            elif op == 1: e = (a % m + b % m) % m
-            elif op == 2: e = (a % m - b % m) % m
+            if op % 10 == 0: e = (a * b) % m
+            elif op % 10 == 1: e = (a % m + b % m) % m
+            elif op % 10 == 2: e = (a % m - b % m) % m
             else: e = pow(a, -1, m)
             exp += _digits(e, W)
         a_ = np.array(A, dtype=np.uint32); b_ = np.array(B, dtype=np.uint32); out = np.zeros(nops * W, dtype=np.uint32)
