@@ -112,9 +112,12 @@ typedef struct SlipState {
 /* LDS layout in 32-bit words */
 #define SLIP_LDS_VARS      0        /* 64 words of workgroup-shared scalars          */
 #define SLIP_LDS_SCAN      64       /* 128 words: per-wave partials of scans/reductions */
-#define SLIP_LDS_WORK      192      /* 2 work lists of SLIP_WORK_CAP (m, i) pairs     */
+#define SLIP_LDS_WORK      192      /* work lists: 2 x SLIP_WORK_CAP (m, i) pairs, or 1 x rows + 1 x 4-word row records */
 #define SLIP_WORK_CAP      1024
-#define SLIP_LDS_BITMAP    (SLIP_LDS_WORK + 2 * 2 * SLIP_WORK_CAP)
+#define SLIP_WORK_WORDS    (6 * SLIP_WORK_CAP)
+#define SLIP_LDS_TAB       (SLIP_LDS_WORK + SLIP_WORK_WORDS)   /* column table: row, len, bits, slab offset per pattern entry */
+#define SLIP_TAB_CAP       1024
+#define SLIP_LDS_BITMAP    (SLIP_LDS_TAB + 4 * SLIP_TAB_CAP)
 
 enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_GEN = 5, SV_LISTN = 6, SV_TMP = 7,
        SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14 };
@@ -580,20 +583,29 @@ SLIP_DEV uint64_t slip_top64(const dig_t *X, int l)
 
 /* rows[t] (one-limb values, never updated: h < 0) times the long pivot M: the pivot's digits stay in
  * registers, every wave takes rows in turn (slip_REF_triangular_solve.c:248-257 for untouched rows) */
-template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, const uint32_t *rows, int nrows)
+template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, const uint32_t *recs, int nrows)
 {
     const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
     const WR<D> Mr = wr_load<D>(Md, slip_abs(M.len));
     int err = 0;
     for (int t = wave; t < nrows; t += nw) {
-        const int r = (int) rows[t];
-        const SlipRow xr = P.xrow[r];
-        const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+        /* record written by the classifying lane: row, low/high digit of the one-limb value, signed length */
+        const int r = (int) recs[4 * t];
+        const int32_t xl = (int32_t) recs[4 * t + 3];
         WR<D> A = wr_zero<D>();
-        if (lane == 0) A.d[0] = (uint32_t) xv;
-        if (lane == 1) A.d[0] = (uint32_t)(xv >> 32);
-        const WR<D> Y = wr_mul<D>(A, slip_abs(xr.len), Mr);
-        err |= slip_store_x_reg<D>(P, r, Y, slip_sgn(xr.len) * slip_sgn(M.len), xr.h);
+        if (lane == 0) A.d[0] = recs[4 * t + 1];
+        if (lane == 1) A.d[0] = recs[4 * t + 2];
+        const WR<D> Y = wr_mul<D>(A, slip_abs(xl), Mr);
+        /* store (no wave-level wait: the rows are next read after a workgroup barrier) */
+        const int len = wr_len<D>(Y);
+        if (len > P.xcap) { err = 1; continue; }
+        wr_store<D>(P.xd + (int64_t) r * P.xcap, Y, (len + 1) & ~1);
+        const uint32_t top = len ? wr_digit<D>(Y, len - 1) : 0u;
+        if (lane == 0) {
+            SlipRow nr; nr.len = (slip_sgn(xl) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = -1; nr.pad = 0;
+            nr.bits = len ? 32 * len - slip_clz32(top) : 0;
+            P.xrow[r] = nr;
+        }
     }
     return err;
 }
@@ -940,7 +952,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     if (k >= 1) {
         volatile int32_t *wcnt = &sv[SV_CNT0], *wcnt2 = &sv[SV_CNT0 + 1];
         if (tid == 0) { *wcnt = 0; *wcnt2 = 0; }
-        uint32_t *wl2 = work + 2 * SLIP_WORK_CAP;
+        uint32_t *wl2 = work + 2 * SLIP_WORK_CAP;          /* 4-word records, SLIP_WORK_CAP of them */
         /* rho[k-1] is the multiplier of every row: stage its digits once (LDS when it fits) */
         const SlipPiv M = P.piv[k - 1];
         const int lm = slip_abs(M.len);
@@ -967,7 +979,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                     } else if (xr.h < 0 && lm + 2 <= P.xcap && lm + 2 <= 256) {
                         /* one limb times a long pivot, no division: wave path with the pivot in registers */
                         const int at = slip_atomic_add_i32((int32_t *) wcnt2, 1);
-                        wl2[at] = (uint32_t) r;
+                        wl2[4 * at] = (uint32_t) r; wl2[4 * at + 1] = (uint32_t) xv; wl2[4 * at + 2] = (uint32_t)(xv >> 32);
+                        wl2[4 * at + 3] = (uint32_t) xr.len;
                         done = 1;
                     } else if (xr.h < 0 && lm + 2 <= P.xcap) {
                         /* beyond 256 digits: this lane walks the pivot's digits */
@@ -1019,9 +1032,22 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     SLIP_STAMP(3);
 
     /* ---- phase 5: column-window cap, then the pivot search ---- */
+    /* column table in LDS (row, signed length, bit length per pattern entry): read once, used by
+     * the cap test, the pivot search, the offsets and the copy below */
+    uint32_t *tab = lds + SLIP_LDS_TAB;
+    const bool use_tab = npat <= SLIP_TAB_CAP;
+    auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[4 * t] : P.row_perm[P.pat[t]]; };
+    auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[4 * t + 1] : P.xrow[P.row_perm[P.pat[t]]].len; };
+    auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[4 * t + 2] : P.xrow[P.row_perm[P.pat[t]]].bits; };
     {
         int mx = 0;
-        for (int t = tid; t < npat; t += T) { int l = slip_abs(P.xrow[P.row_perm[P.pat[t]]].len); if (l > mx) mx = l; }
+        for (int t = tid; t < npat; t += T) {
+            const int r = P.row_perm[P.pat[t]];
+            const SlipRow xr = P.xrow[r];
+            const int l = slip_abs(xr.len);
+            if (l > mx) mx = l;
+            if (use_tab) { tab[4 * t] = (uint32_t) r; tab[4 * t + 1] = (uint32_t) xr.len; tab[4 * t + 2] = (uint32_t) xr.bits; tab[4 * t + 3] = 0; }
+        }
         if (mx > 0) slip_atomic_max_i32((int32_t *) &sv[SV_MAXDIG], mx);
         slip_block_sync();
     }
@@ -1037,9 +1063,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     {
         uint64_t k1 = ~0ull;                                     /* (key, t) packed: smaller is better */
         for (int t = tid; t < nL; t += T) {
-            const SlipRow xr = P.xrow[P.row_perm[P.pat[nU + t]]];
-            if (xr.len == 0) continue;
-            const uint64_t key = kind == 2 ? 0 : (kind == 0 ? (uint64_t) xr.bits : (uint64_t)(0x7FFFFFFF - xr.bits));
+            if (ent_len(nU + t) == 0) continue;
+            const int bits = ent_bits(nU + t);
+            const uint64_t key = kind == 2 ? 0 : (kind == 0 ? (uint64_t) bits : (uint64_t)(0x7FFFFFFF - bits));
             const uint64_t c = (key << 32) | (uint32_t) t;
             if (c < k1) k1 = c;
         }
@@ -1049,12 +1075,12 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         else {
             const uint32_t bkey = (uint32_t)(k1 >> 32);
             const int bbits = kind == 0 ? (int) bkey : 0x7FFFFFFF - (int) bkey;
+            /* leading 64 bits of the candidates of the winning bit-length class; kept for the tie pass */
             uint64_t k2 = ~0ull;
             for (int t = tid; t < nL; t += T) {
-                const int r = P.row_perm[P.pat[nU + t]];
-                const SlipRow xr = P.xrow[r];
-                if (xr.len == 0 || xr.bits != bbits) continue;
-                const uint64_t top = slip_top64(P.xd + (int64_t) r * P.xcap, slip_abs(xr.len));
+                const int32_t xl = ent_len(nU + t);
+                if (xl == 0 || ent_bits(nU + t) != bbits) continue;
+                const uint64_t top = slip_top64(P.xd + (int64_t) ent_row(nU + t) * P.xcap, slip_abs(xl));
                 const uint64_t key = kind == 0 ? top : ~top;
                 if (key < k2) k2 = key;
             }
@@ -1062,10 +1088,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             if (tid == 0) sv[SV_LISTN] = 0;
             slip_block_sync();
             for (int t = tid; t < nL; t += T) {
-                const int r = P.row_perm[P.pat[nU + t]];
-                const SlipRow xr = P.xrow[r];
-                if (xr.len == 0 || xr.bits != bbits) continue;
-                const uint64_t top = slip_top64(P.xd + (int64_t) r * P.xcap, slip_abs(xr.len));
+                const int32_t xl = ent_len(nU + t);
+                if (xl == 0 || ent_bits(nU + t) != bbits) continue;
+                const uint64_t top = slip_top64(P.xd + (int64_t) ent_row(nU + t) * P.xcap, slip_abs(xl));
                 if ((kind == 0 ? top : ~top) != m2) continue;
                 const int at = slip_atomic_add_i32((int32_t *) &sv[SV_LISTN], 1);
                 if (at < 2 * SLIP_WORK_CAP) work[at] = (uint32_t) t;
@@ -1079,28 +1104,27 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                     if (best < 0) { best = t; continue; }
                     int cmp = 0;
                     if (bbits > 64) {
-                        const int rb = P.row_perm[P.pat[nU + best]], r = P.row_perm[P.pat[nU + t]];
-                        cmp = wb_cmp(P.xd + (int64_t) rb * P.xcap, slip_abs(P.xrow[rb].len),
-                                     P.xd + (int64_t) r * P.xcap, slip_abs(P.xrow[r].len));
+                        const int rb = ent_row(nU + best), r = ent_row(nU + t);
+                        cmp = wb_cmp(P.xd + (int64_t) rb * P.xcap, slip_abs(ent_len(nU + best)),
+                                     P.xd + (int64_t) r * P.xcap, slip_abs(ent_len(nU + t)));
                     }
                     if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && t < best)) best = t;
                 }
             } else {                                              /* too many ties for the list */
                 for (int t = 0; t < nL; t++) {
-                    const int r = P.row_perm[P.pat[nU + t]];
-                    const SlipRow xr = P.xrow[r];
-                    if (xr.len == 0 || xr.bits != bbits) continue;
+                    const int32_t xl = ent_len(nU + t);
+                    if (xl == 0 || ent_bits(nU + t) != bbits) continue;
                     if (best < 0) { best = t; continue; }
-                    const int rb = P.row_perm[P.pat[nU + best]];
-                    const int cmp = wb_cmp(P.xd + (int64_t) rb * P.xcap, slip_abs(P.xrow[rb].len),
-                                           P.xd + (int64_t) r * P.xcap, slip_abs(xr.len));
+                    const int rb = ent_row(nU + best), r = ent_row(nU + t);
+                    const int cmp = wb_cmp(P.xd + (int64_t) rb * P.xcap, slip_abs(ent_len(nU + best)),
+                                           P.xd + (int64_t) r * P.xcap, slip_abs(xl));
                     if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0)) best = t;
                 }
             }
             slip_block_sync();
         }
     }
-    int pivrow = P.row_perm[P.pat[nU + best]];
+    int pivrow = ent_row(nU + best);
     /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146) */
     if (scheme == 1 || scheme == 3 || scheme == 4) {
         const int pc = P.pinv[col];
@@ -1140,13 +1164,22 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     const int nUe = nU + 1, nE = nUe + nL;
     const int64_t Lnz = sv64[SV_LNZ / 2], Lnl = sv64[SV_LNL / 2], Unz = sv64[SV_UNZ / 2], Unl = sv64[SV_UNL / 2];
     uint64_t baseU = 0, baseL = 0;
+    /* pattern index of output entry e: U part, then the pivot (L position `pividx`), then the L part */
+    int pividx = nU + best;
+    if (pivrow != ent_row(nU + best)) {               /* the diagonal was preferred: find it in the L part */
+        if (tid == 0) sv[SV_TMP] = -1;
+        slip_block_sync();
+        for (int t = tid; t < nL; t += T) if (ent_row(nU + t) == pivrow) sv[SV_TMP] = nU + t;
+        slip_block_sync();
+        pividx = sv[SV_TMP];
+    }
     for (int e0 = 0; e0 < nE; e0 += T) {
         const int e = e0 + tid;
-        int r = -1; uint64_t lu = 0, ll = 0; SlipRow xr; xr.len = 0; xr.bits = 0; xr.h = 0; xr.pad = 0;
+        int r = -1, pt = 0; uint64_t lu = 0, ll = 0; int32_t xl = 0; int xb = 0;
         if (e < nE) {
-            r = e < nU ? P.row_perm[P.pat[e]] : (e == nU ? pivrow : P.row_perm[P.pat[e - 1]]);
-            xr = P.xrow[r];
-            if (e < nUe) lu = (uint64_t) slip_limbs(xr.len); else ll = (uint64_t) slip_limbs(xr.len);
+            pt = e < nU ? e : (e == nU ? pividx : e - 1);
+            r = ent_row(pt); xl = ent_len(pt); xb = ent_bits(pt);
+            if (e < nUe) lu = (uint64_t) slip_limbs(xl); else ll = (uint64_t) slip_limbs(xl);
         }
         uint64_t eu, el, tu, tl;
         slip_block_scan2(lu, ll, scan_tmp, &eu, &el, &tu, &tl);
@@ -1154,10 +1187,11 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             /* capacity is verified before anything is committed; these records are provisional */
             if (e < nUe) {
                 const int64_t at = Unz + e;
-                if (at < P.Ucap_nz) { P.Ui[at] = r; SlipEnt en; en.off = Unl + (int64_t)(baseU + eu); en.len = xr.len; en.bits = xr.bits; P.Ue[at] = en; }
+                if (at < P.Ucap_nz) { P.Ui[at] = r; SlipEnt en; en.off = Unl + (int64_t)(baseU + eu); en.len = xl; en.bits = xb; P.Ue[at] = en; }
             } else {
                 const int64_t at = Lnz + (e - nUe);
-                if (at < P.Lcap_nz) { P.Li[at] = r; SlipEnt en; en.off = Lnl + (int64_t)(baseL + el); en.len = xr.len; en.bits = xr.bits; P.Le[at] = en; }
+                if (at < P.Lcap_nz) { P.Li[at] = r; SlipEnt en; en.off = Lnl + (int64_t)(baseL + el); en.len = xl; en.bits = xb; P.Le[at] = en; }
+                if (use_tab) tab[4 * pt + 3] = (uint32_t)(baseL + el);      /* L slab offset relative to Lnl */
             }
         }
         baseU += tu; baseL += tl;
@@ -1167,16 +1201,24 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     if (Lnz + nL > P.Lcap_nz || Lnl + (int64_t) totL > P.Lcap_nl) return SLIPDEV_GROW_L;
     slip_block_sync();
     SLIP_STAMP(5);
-    /* limbs: one wave per entry, coalesced */
+    /* limbs: one wave per entry, coalesced; x rows are stored padded to whole limbs and nobody reads
+     * the slabs before the barrier below */
     for (int e = wave; e < nE; e += nw) {
         const int isU = e < nUe;
-        const int64_t at = isU ? Unz + e : Lnz + (e - nUe);
-        const int r = isU ? P.Ui[at] : P.Li[at];
-        const SlipEnt en = isU ? P.Ue[at] : P.Le[at];
-        dig_t *dst = isU ? (dig_t *)(P.Ulimbs + en.off) : (dig_t *)(P.Llimbs + en.off);
-        /* x rows are stored padded to whole limbs; nobody reads the slab before the barrier below */
+        int r; int32_t xl; dig_t *dst;
+        if (use_tab && !isU) {
+            const int pt = e - 1;
+            r = (int) tab[4 * pt]; xl = (int32_t) tab[4 * pt + 1];
+            dst = (dig_t *)(P.Llimbs + Lnl + (int64_t) tab[4 * pt + 3]);
+        } else {
+            const int64_t at = isU ? Unz + e : Lnz + (e - nUe);
+            r = isU ? P.Ui[at] : P.Li[at];
+            const SlipEnt en = isU ? P.Ue[at] : P.Le[at];
+            xl = en.len;
+            dst = isU ? (dig_t *)(P.Ulimbs + en.off) : (dig_t *)(P.Llimbs + en.off);
+        }
         const dig_t *srcx = P.xd + (int64_t) r * P.xcap;
-        const int lw = (slip_abs(en.len) + 1) & ~1;
+        const int lw = (slip_abs(xl) + 1) & ~1;
         for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = srcx[c];
     }
     slip_block_sync();
@@ -1184,15 +1226,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     /* pivot bookkeeping (slip_get_pivot.c:164-182); wave 0 */
     if (wave == 0) {
         /* position of the pivot inside L(:,k): `best` unless the diagonal was preferred */
-        int found = best;
-        if (P.Li[Lnz + best] != pivrow) {
-            found = -1;
-            for (int t0 = 0; t0 < nL && found < 0; t0 += SLIP_WAVE) {
-                const int t = t0 + lane;
-                const uint64_t hit = slip_ballot(t < nL && P.Li[Lnz + t] == pivrow);
-                if (hit) found = t0 + slip_ctz64(hit);
-            }
-        }
+        const int found = pividx - nU;
         const SlipEnt pe = P.Le[Lnz + found];
         const int lp_ = slip_abs(pe.len);
         const dig_t *pv = (const dig_t *)(P.Llimbs + pe.off);

@@ -354,7 +354,7 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n)); A_(dev_alloc(&P->xrow, n));
     A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->pat, n));
     A_(dev_alloc(&P->gbitmap, (int64_t)(n + 31) / 32 + 64));
-    A_(dev_alloc(&P->batch, 1)); A_(dev_alloc(&P->batch_items, 2 * 2 * SLIP_WORK_CAP)); A_(dev_alloc(&P->dbg, 4 * 256));
+    A_(dev_alloc(&P->batch, 1)); A_(dev_alloc(&P->batch_items, SLIP_WORK_WORDS)); A_(dev_alloc(&P->dbg, 4 * 256));
     if (!rc && hipMemset(P->dbg, 0, 4 * 256 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc && hipMemset(P->batch, 0, sizeof(SlipBatch)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     /* initial sizes: S->lnz/unz only size the first allocation in the reference too */
