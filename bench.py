@@ -81,17 +81,13 @@ def main():
     import numpy as np
     import torch
     import slip_lu_amd as sl
+    from slip_lu_amd import parallel
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = parallel.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist = parallel.init("nccl")          # RCCL; None when there is one rank
 
     w = WORKLOAD
     Ap, Ai, Ax = sl.matgen(w["n"], w["density"], w["bits"], w["seed"])
@@ -121,10 +117,7 @@ def main():
         kernel_ms += f.info()["kernel_ms"]
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(dist, elapsed, device="cuda")
 
     info = f.info()
     K = info["K"]
@@ -133,6 +126,32 @@ def main():
     idx = {e["name"]: e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "index.json")))}[w["golden"]]
     assert K == idx["K"] and nnz == idx["lnz"] + idx["unz"] - idx["K"], "benchmark run differs from the reference window"
     assert info["b_read"] == idx["counters"]["B_read"] and info["b_write"] == idx["counters"]["B_write"]
+
+    # HBM traffic per launch from the PMC passes of this round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # separate runs; profiles/r01/v3_pmc_summary.json): counters cannot be read from inside this process
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01", "v3_pmc_summary.json")))["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+
+    # secondary, complete-run workloads (LP bases / ExampleMats of the reference): one run each
+    secondary = []
+    if rank == 0 and world == 1:
+        from conftest import load_case
+        for name in ("10teams", "prob159", "NSR8K_w600", "rl5934"):
+            try:
+                e, fx = load_case(name)
+                g = sl.Factorization(e["n"], fx["Ap"], fx["Ai"], fx["Alen"], fx["Alimbs"], fx["q"], limb_cap=e["cap"])
+                g.run(e["kmax"]); g.reset(); g.run(e["kmax"])
+                gi = g.info(); g.close()
+                nz = gi["lnz"] + gi["unz"] - gi["K"]
+                assert nz == e["lnz"] + e["unz"] - e["K"] and gi["b_read"] == e["counters"]["B_read"]
+                secondary.append(dict(workload=name, columns=gi["K"], lu_nnz=nz, max_limbs=gi["max_limbs"],
+                                      kernel_ms=gi["kernel_ms"], lu_nnz_per_s=nz / (gi["kernel_ms"] * 1e-3),
+                                      reference_cpu_seconds_build_container=e["ref_seconds"]))
+            except Exception as ex:                  # never let a side measurement break the headline
+                secondary.append(dict(workload=name, error=str(ex)))
 
     ms_per_step = 1e3 * elapsed / args.steps
     kms = kernel_ms / args.steps                       # HIP-event time of the column-loop kernel per launch
@@ -148,11 +167,13 @@ def main():
                    "columns": K, "lu_nnz": nnz, "n_upd": info["n_upd"], "max_limbs": info["max_limbs"],
                    "parallelism": "replicas" if world > 1 else "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "slip_factor_kernel", "kernel_ms_per_launch": kms,
                      "algorithmic_read_bytes": info["b_read"], "algorithmic_write_bytes": info["b_write"],
                      "achieved_read_plus_write": (info["b_read"] + info["b_write"]) / (kms * 1e-3) / 1e9},
     }
+    if secondary:
+        out["secondary"] = secondary
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(K, nnz)
     f.close()

@@ -626,29 +626,25 @@ SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, 
     return slip_history_wave(P, r, k - 1, P.xrow[r].h, b0, b1, b2, mode, publish);
 }
 
-/* Process the nq queued items of list wl (LDS).  Called by all threads right after a workgroup barrier;
- * returns after a workgroup barrier with every item done and visible.  Errors land in sv[SV_ERR]. */
-SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, int jn, int k, int64_t m0, int nq,
-                         const uint32_t *wl, dig_t *b0, dig_t *b1, dig_t *b2)
+/* Queue processing in two halves so that the caller can overlap its own work with the helpers:
+ *   slip_drain_begin: (fork only) prepare the shared inverse cache, publish the batch; returns 1 if forked
+ *   slip_drain_end:   this workgroup's share (or the whole queue when not forked), wait for the helpers
+ * Both are called by all threads after a workgroup barrier; _end returns after a workgroup barrier with
+ * every item done and visible.  Errors land in sv[SV_ERR]. */
+SLIP_DEV int slip_drain_begin(const SlipParams &P, uint32_t *lds, int kind, int j, int jn, int k, int64_t m0, int nq,
+                              const uint32_t *wl, dig_t *b0, dig_t *b1, dig_t *b2)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     const int fork = P.fork_min > 0 && nq >= P.fork_min;
-    if (!fork) {
-        for (int t = wave; t < nq; t += nw) {
-            const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 1);
-            if (e && lane == 0) sv[SV_ERR] = e;
-        }
-        slip_block_sync();
-        return;
-    }
+    if (!fork) return 0;
     /* 1. the shared inverse cache must cover the batch before other CUs read it */
     for (int t = wave; t < nq; t += nw) {
         const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 1, 1);
         if (e && lane == 0) sv[SV_ERR] = e;
     }
     slip_block_sync();
-    if (sv[SV_ERR]) return;
+    if (sv[SV_ERR]) return 0;                 /* _end will see the error and do nothing */
     /* 2. publish: items and descriptor to HBM, agent-scope release, bump the generation */
     SlipBatch *B = P.batch;
     const int nwords = kind == 1 ? 2 * nq : nq;
@@ -659,18 +655,38 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
     }
     slip_vm_drain();
     slip_block_sync();
-    const int H = P.nhelpers;
-    if (tid == 0 && H > 0) {
+    if (tid == 0 && P.nhelpers > 0) {
         slip_agent_release();
         const int g = sv[SV_GEN] + 1;
         sv[SV_GEN] = g;
         slip_agent_store_i32(&B->seq, g);
     }
-    /* 3. this workgroup's share (global wave index = wave, stride over all waves of all workgroups) */
-    for (int t = wave; t < nq; t += nw * (H + 1)) {
-        const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 0);
-        if (e && lane == 0) sv[SV_ERR] = e == 2 ? 7 : e;
+    return 1;
+}
+
+SLIP_DEV void slip_drain_end(const SlipParams &P, uint32_t *lds, int forked, int kind, int j, int jn, int k, int64_t m0, int nq,
+                             const uint32_t *wl, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    const int tid = slip_tid(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    if (!forked) {
+        if (!sv[SV_ERR])
+            for (int t = wave; t < nq; t += nw) {
+                const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 1);
+                if (e && lane == 0) sv[SV_ERR] = e;
+            }
+        slip_block_sync();
+        return;
     }
+    SlipBatch *B = P.batch;
+    const int H = P.nhelpers;
+    /* 3. with helpers present the master keeps its waves free for its own work (it is the critical path);
+     *    without helpers (tests) it does the published batch itself */
+    if (H == 0)
+        for (int t = wave; t < nq; t += nw) {
+            const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 0);
+            if (e && lane == 0) sv[SV_ERR] = e == 2 ? 7 : e;
+        }
     /* 4. wait for the helpers, then acquire what they wrote */
     slip_vm_drain();
     slip_block_sync();
@@ -689,6 +705,13 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
         }
         slip_block_sync();
     }
+}
+
+SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, int jn, int k, int64_t m0, int nq,
+                         const uint32_t *wl, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    const int forked = slip_drain_begin(P, lds, kind, j, jn, k, m0, nq, wl, b0, b1, b2);
+    slip_drain_end(P, lds, forked, kind, j, jn, k, m0, nq, wl, b0, b1, b2);
 }
 
 /* helper workgroups: wait for batches, do their share, report */
@@ -728,7 +751,7 @@ SLIP_DEV void slip_helper_loop(const SlipParams &P, const SlipState *st, uint32_
         if (tid == 0) { P.dbg[4 * slip_block()] = s; P.dbg[4 * slip_block() + 1] = 2; P.dbg[4 * slip_block() + 2] = kind; P.dbg[4 * slip_block() + 3] = nitems; }
         if (kind == 0) { if (tid == 0) P.dbg[4 * slip_block() + 1] = 4; return; }     /* the column loop has ended */
         const int64_t m0 = B->m0;
-        for (int t = slip_block() * nw + wave; t < nitems; t += nw * (H + 1)) {
+        for (int t = (slip_block() - 1) * nw + wave; t < nitems; t += nw * H) {
             const int e = slip_run_item(P, kind, j, jn, k, m0, P.batch_items, t, b0, b1, b2, 0, 0);
             if (e && lane == 0) sv[SV_ERR] = e == 2 ? 8 : 1;      /* 1: a buffer is too small (the host grows it) */
         }
@@ -1006,6 +1029,13 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             }
             slip_block_sync();
             SLIP_STAMP(9);
+            const int nq = *wcnt;
+#ifdef SLIP_PROFILING
+            if (tid == 0) st->prof[11] += (unsigned long long) nq;
+#endif
+            /* the history rows that need a division go to the helpers first; the one-limb-times-pivot rows
+             * are multiplied here meanwhile */
+            const int forked = slip_drain_begin(P, lds, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
             {
                 const int n2 = *wcnt2;
                 if (n2 > 0) {
@@ -1018,11 +1048,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                     if (e && lane == 0) sv[SV_ERR] = 1;
                 }
             }
-            const int nq = *wcnt;
-#ifdef SLIP_PROFILING
-            if (tid == 0) st->prof[11] += (unsigned long long) nq;
-#endif
-            slip_drain(P, lds, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
+            slip_drain_end(P, lds, forked, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
             SLIP_STAMP(10);
             if (tid == 0) { *wcnt = 0; *wcnt2 = 0; }
             slip_block_sync();
