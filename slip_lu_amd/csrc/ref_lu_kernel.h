@@ -73,6 +73,7 @@ typedef struct SlipParams {
     struct SlipBatch *batch; uint32_t *batch_items;
     int32_t nhelpers, fork_min;                     /* fork_min: queue length from which a batch is published */
     int32_t seq0, pad1;                             /* hand-off generation at launch (SlipState.seq)          */
+    int32_t bitmap_in_lds, scratch_in_lds;          /* where the bitmap / wave scratch live (generic kernel)  */
     int32_t *dbg;                                   /* 4 words per workgroup: hand-off diagnostics            */
 } SlipParams;
 
@@ -95,7 +96,8 @@ typedef struct SlipBatch {
 typedef struct SlipState {
     int32_t k_next, status, status_k;
     int32_t seq;                                    /* batch generation: monotonic across launches */
-    int64_t Lnz, Lnl, Unz, Unl;
+    int64_t Lnz, Lnl, Unz, Unl;                     /* Lnl counts allocated limbs (a direct row may leave one limb unused) */
+    int64_t Lnl_exact, pad64;                       /* limbs actually stored in L                                          */
     unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig;
     unsigned long long prof[12];                    /* -DSLIP_PROFILE_PHASES builds only */
 } SlipState;
@@ -120,7 +122,8 @@ typedef struct SlipState {
 #define SLIP_LDS_BITMAP    (SLIP_LDS_TAB + 4 * SLIP_TAB_CAP)
 
 enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_GEN = 5, SV_LISTN = 6, SV_TMP = 7,
-       SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14 };
+       SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14,
+       SV_LALLOC = 16 /* limbs of the L slab handed out to this column's direct rows */, SV_LEXACT = 18, SV_LNLX = 20 };
 
 SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
 SLIP_DEV int slip_abs(int32_t v) { return v < 0 ? -v : v; }
@@ -583,31 +586,33 @@ SLIP_DEV uint64_t slip_top64(const dig_t *X, int l)
 
 /* rows[t] (one-limb values, never updated: h < 0) times the long pivot M: the pivot's digits stay in
  * registers, every wave takes rows in turn (slip_REF_triangular_solve.c:248-257 for untouched rows) */
-template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, const uint32_t *recs, int nrows)
+template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, const uint32_t *recs, int nrows,
+                                                int64_t slab_base)
 {
     const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
     const WR<D> Mr = wr_load<D>(Md, slip_abs(M.len));
-    int err = 0;
     for (int t = wave; t < nrows; t += nw) {
-        /* record written by the classifying lane: row, low/high digit of the one-limb value, signed length */
-        const int r = (int) recs[4 * t];
-        const int32_t xl = (int32_t) recs[4 * t + 3];
+        /* record written by the classifying lane: row, low/high digit of the one-limb value, signed length,
+         * and the slot of the L slab reserved for the product (these rows ARE L(:,k): no second copy) */
+        const int r = (int) recs[5 * t];
+        const int32_t xl = (int32_t) recs[5 * t + 3];
+        const int64_t off = slab_base + (int64_t) recs[5 * t + 4];
         WR<D> A = wr_zero<D>();
-        if (lane == 0) A.d[0] = recs[4 * t + 1];
-        if (lane == 1) A.d[0] = recs[4 * t + 2];
+        if (lane == 0) A.d[0] = recs[5 * t + 1];
+        if (lane == 1) A.d[0] = recs[5 * t + 2];
         const WR<D> Y = wr_mul<D>(A, slip_abs(xl), Mr);
-        /* store (no wave-level wait: the rows are next read after a workgroup barrier) */
         const int len = wr_len<D>(Y);
-        if (len > P.xcap) { err = 1; continue; }
-        wr_store<D>(P.xd + (int64_t) r * P.xcap, Y, (len + 1) & ~1);
+        wr_store<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
         const uint32_t top = len ? wr_digit<D>(Y, len - 1) : 0u;
         if (lane == 0) {
-            SlipRow nr; nr.len = (slip_sgn(xl) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = -1; nr.pad = 0;
+            SlipRow nr; nr.len = (slip_sgn(xl) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = -1;
+            nr.pad = 1;                                          /* the value lives in the L slab ... */
             nr.bits = len ? 32 * len - slip_clz32(top) : 0;
             P.xrow[r] = nr;
+            *(int64_t *)(P.xd + (int64_t) r * P.xcap) = off;     /* ... at this limb offset */
         }
     }
-    return err;
+    return 0;
 }
 
 /* ------------------------------------------------------------------ */
@@ -770,12 +775,15 @@ SLIP_DEV void slip_helper_loop(const SlipParams &P, const SlipState *st, uint32_
 /* ------------------------------------------------------------------ */
 /* one column; returns a SLIPDEV_* status (0 = committed)              */
 /* ------------------------------------------------------------------ */
-template <bool BM_LDS, bool SCR_LDS>
+/* FAST: bitmap and wave scratch both in LDS (addresses provably LDS, ds_* instructions);
+ * otherwise the generic build picks either place at run time (flat addressing). */
+template <bool FAST>
 SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uint32_t *lds,
                             unsigned long long *t_read, unsigned long long *t_upd,
                             unsigned long long *t_src, unsigned long long *t_str)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
     const int col = P.q[k];
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     volatile int64_t *sv64 = (volatile int64_t *)(lds + SLIP_LDS_VARS);
@@ -791,7 +799,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
 
     /* ---- phase 0: clear the pattern bitmap ---- */
     for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
-    if (tid == 0) { sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; }
+    if (tid == 0) { sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv64[SV_LALLOC / 2] = 0; sv64[SV_LEXACT / 2] = 0; }
     slip_block_sync();
 
     /* ---- phase 1: scatter A(:,col) into x (slip_REF_triangular_solve.c:105-119) ---- */
@@ -975,7 +983,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     if (k >= 1) {
         volatile int32_t *wcnt = &sv[SV_CNT0], *wcnt2 = &sv[SV_CNT0 + 1];
         if (tid == 0) { *wcnt = 0; *wcnt2 = 0; }
-        uint32_t *wl2 = work + 2 * SLIP_WORK_CAP;          /* 4-word records, SLIP_WORK_CAP of them */
+        uint32_t *wl2 = work + SLIP_WORK_CAP;              /* 5-word records, SLIP_WORK_CAP of them */
         /* rho[k-1] is the multiplier of every row: stage its digits once (LDS when it fits) */
         const SlipPiv M = P.piv[k - 1];
         const int lm = slip_abs(M.len);
@@ -986,8 +994,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         slip_block_sync();
         SLIP_STAMP(8);
         uint32_t *wl = work;
+        const unsigned long long slot = (unsigned long long)((lm + 3) >> 1);
         for (int t0 = 0; t0 < nL; t0 += SLIP_WORK_CAP) {
             const int te = t0 + SLIP_WORK_CAP < nL ? t0 + SLIP_WORK_CAP : nL;
+            const unsigned long long chunk_base = (unsigned long long) sv64[SV_LALLOC / 2];
             for (int t = t0 + tid; t < te; t += T) {
                 const int r = P.row_perm[P.pat[nU + t]];
                 const SlipRow xr = P.xrow[r];
@@ -1001,9 +1011,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                         done = 1;
                     } else if (xr.h < 0 && lm + 2 <= P.xcap && lm + 2 <= 256) {
                         /* one limb times a long pivot, no division: wave path with the pivot in registers */
+                        /* every such row gets a slot of (lm+3)/2 limbs in the L slab (the product has at most lm+2 digits) */
                         const int at = slip_atomic_add_i32((int32_t *) wcnt2, 1);
-                        wl2[4 * at] = (uint32_t) r; wl2[4 * at + 1] = (uint32_t) xv; wl2[4 * at + 2] = (uint32_t)(xv >> 32);
-                        wl2[4 * at + 3] = (uint32_t) xr.len;
+                        wl2[5 * at] = (uint32_t) r; wl2[5 * at + 1] = (uint32_t) xv; wl2[5 * at + 2] = (uint32_t)(xv >> 32);
+                        wl2[5 * at + 3] = (uint32_t) xr.len; wl2[5 * at + 4] = (uint32_t)(chunk_base + (unsigned long long) at * slot);
                         done = 1;
                     } else if (xr.h < 0 && lm + 2 <= P.xcap) {
                         /* beyond 256 digits: this lane walks the pivot's digits */
@@ -1029,6 +1040,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             }
             slip_block_sync();
             SLIP_STAMP(9);
+            /* the slots handed out above must exist before anything is written into them */
+            const unsigned long long lalloc_now = chunk_base + (unsigned long long) *wcnt2 * slot;
+            if (sv64[SV_LNL / 2] + (int64_t) lalloc_now > P.Lcap_nl) return SLIPDEV_GROW_L;
             const int nq = *wcnt;
 #ifdef SLIP_PROFILING
             if (tid == 0) st->prof[11] += (unsigned long long) nq;
@@ -1041,16 +1055,17 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                 if (n2 > 0) {
                     const int Dm = (lm + 2 + 63) >> 6;
                     int e;
-                    if (Dm <= 1) e = slip_mul_rows_reg<1>(P, M, Md, wl2, n2);
-                    else if (Dm == 2) e = slip_mul_rows_reg<2>(P, M, Md, wl2, n2);
-                    else if (Dm == 3) e = slip_mul_rows_reg<3>(P, M, Md, wl2, n2);
-                    else e = slip_mul_rows_reg<4>(P, M, Md, wl2, n2);
+                    const int64_t sb = sv64[SV_LNL / 2];
+                    if (Dm <= 1) e = slip_mul_rows_reg<1>(P, M, Md, wl2, n2, sb);
+                    else if (Dm == 2) e = slip_mul_rows_reg<2>(P, M, Md, wl2, n2, sb);
+                    else if (Dm == 3) e = slip_mul_rows_reg<3>(P, M, Md, wl2, n2, sb);
+                    else e = slip_mul_rows_reg<4>(P, M, Md, wl2, n2, sb);
                     if (e && lane == 0) sv[SV_ERR] = 1;
                 }
             }
             slip_drain_end(P, lds, forked, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
             SLIP_STAMP(10);
-            if (tid == 0) { *wcnt = 0; *wcnt2 = 0; }
+            if (tid == 0) { *wcnt = 0; *wcnt2 = 0; sv64[SV_LALLOC / 2] = (int64_t) lalloc_now; }
             slip_block_sync();
         }
     }
@@ -1062,9 +1077,20 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
      * the cap test, the pivot search, the offsets and the copy below */
     uint32_t *tab = lds + SLIP_LDS_TAB;
     const bool use_tab = npat <= SLIP_TAB_CAP;
+    const int64_t Lnl0 = sv64[SV_LNL / 2];              /* L slab cursor at the start of this column */
     auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[4 * t] : P.row_perm[P.pat[t]]; };
     auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[4 * t + 1] : P.xrow[P.row_perm[P.pat[t]]].len; };
     auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[4 * t + 2] : P.xrow[P.row_perm[P.pat[t]]].bits; };
+    /* where the digits of a row are: its x row, or (rows multiplied straight into L) the slab */
+    auto row_digits = [&](int r) -> const dig_t * {
+        const dig_t *X = P.xd + (int64_t) r * P.xcap;
+        return P.xrow[r].pad ? (const dig_t *)(P.Llimbs + *(const int64_t *) X) : X;
+    };
+    auto ent_digits = [&](int t) -> const dig_t * {
+        if (use_tab) return (tab[4 * t + 3] >> 31) ? (const dig_t *)(P.Llimbs + Lnl0 + (int64_t)(tab[4 * t + 3] & 0x7FFFFFFFu))
+                                                  : P.xd + (int64_t) tab[4 * t] * P.xcap;
+        return row_digits(P.row_perm[P.pat[t]]);
+    };
     {
         int mx = 0;
         for (int t = tid; t < npat; t += T) {
@@ -1072,7 +1098,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             const SlipRow xr = P.xrow[r];
             const int l = slip_abs(xr.len);
             if (l > mx) mx = l;
-            if (use_tab) { tab[4 * t] = (uint32_t) r; tab[4 * t + 1] = (uint32_t) xr.len; tab[4 * t + 2] = (uint32_t) xr.bits; tab[4 * t + 3] = 0; }
+            if (use_tab) {
+                tab[4 * t] = (uint32_t) r; tab[4 * t + 1] = (uint32_t) xr.len; tab[4 * t + 2] = (uint32_t) xr.bits;
+                tab[4 * t + 3] = xr.pad ? (0x80000000u | (uint32_t)(*(const int64_t *)(P.xd + (int64_t) r * P.xcap) - Lnl0)) : 0u;
+            }
         }
         if (mx > 0) slip_atomic_max_i32((int32_t *) &sv[SV_MAXDIG], mx);
         slip_block_sync();
@@ -1106,7 +1135,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             for (int t = tid; t < nL; t += T) {
                 const int32_t xl = ent_len(nU + t);
                 if (xl == 0 || ent_bits(nU + t) != bbits) continue;
-                const uint64_t top = slip_top64(P.xd + (int64_t) ent_row(nU + t) * P.xcap, slip_abs(xl));
+                const uint64_t top = slip_top64(ent_digits(nU + t), slip_abs(xl));
                 const uint64_t key = kind == 0 ? top : ~top;
                 if (key < k2) k2 = key;
             }
@@ -1116,7 +1145,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             for (int t = tid; t < nL; t += T) {
                 const int32_t xl = ent_len(nU + t);
                 if (xl == 0 || ent_bits(nU + t) != bbits) continue;
-                const uint64_t top = slip_top64(P.xd + (int64_t) ent_row(nU + t) * P.xcap, slip_abs(xl));
+                const uint64_t top = slip_top64(ent_digits(nU + t), slip_abs(xl));
                 if ((kind == 0 ? top : ~top) != m2) continue;
                 const int at = slip_atomic_add_i32((int32_t *) &sv[SV_LISTN], 1);
                 if (at < 2 * SLIP_WORK_CAP) work[at] = (uint32_t) t;
@@ -1129,11 +1158,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                     const int t = (int) work[c];
                     if (best < 0) { best = t; continue; }
                     int cmp = 0;
-                    if (bbits > 64) {
-                        const int rb = ent_row(nU + best), r = ent_row(nU + t);
-                        cmp = wb_cmp(P.xd + (int64_t) rb * P.xcap, slip_abs(ent_len(nU + best)),
-                                     P.xd + (int64_t) r * P.xcap, slip_abs(ent_len(nU + t)));
-                    }
+                    if (bbits > 64)
+                        cmp = wb_cmp(ent_digits(nU + best), slip_abs(ent_len(nU + best)), ent_digits(nU + t), slip_abs(ent_len(nU + t)));
                     if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && t < best)) best = t;
                 }
             } else {                                              /* too many ties for the list */
@@ -1141,9 +1167,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                     const int32_t xl = ent_len(nU + t);
                     if (xl == 0 || ent_bits(nU + t) != bbits) continue;
                     if (best < 0) { best = t; continue; }
-                    const int rb = ent_row(nU + best), r = ent_row(nU + t);
-                    const int cmp = wb_cmp(P.xd + (int64_t) rb * P.xcap, slip_abs(ent_len(nU + best)),
-                                           P.xd + (int64_t) r * P.xcap, slip_abs(xl));
+                    const int cmp = wb_cmp(ent_digits(nU + best), slip_abs(ent_len(nU + best)), ent_digits(nU + t), slip_abs(xl));
                     if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0)) best = t;
                 }
             }
@@ -1161,7 +1185,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             else if (P.tol_mode == 0) take = 1;
             else {
                 const dig_t *num, *den; int ln, ldn;
-                const dig_t *xp = P.xd + (int64_t) pivrow * P.xcap, *xc = P.xd + (int64_t) col * P.xcap;
+                const dig_t *xp = row_digits(pivrow), *xc = row_digits(col);
                 const int lp_ = slip_abs(P.xrow[pivrow].len), lc_ = slip_abs(P.xrow[col].len);
                 if (scheme == 3) { num = xp; ln = lp_; den = xc; ldn = lc_; }   /* |small| / |diag| >= tol */
                 else             { num = xc; ln = lc_; den = xp; ldn = lp_; }   /* |diag| / |large| >= tol */
@@ -1199,13 +1223,23 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         slip_block_sync();
         pividx = sv[SV_TMP];
     }
+    /* rows multiplied straight into the L slab (phase 4) already own the first `lalloc` limbs behind Lnl;
+     * the other L rows are copied behind them */
+    const uint64_t lalloc = (uint64_t) sv64[SV_LALLOC / 2];
+    uint64_t dirL = 0;                                   /* exact limbs of the direct rows (channel packed with U) */
     for (int e0 = 0; e0 < nE; e0 += T) {
         const int e = e0 + tid;
-        int r = -1, pt = 0; uint64_t lu = 0, ll = 0; int32_t xl = 0; int xb = 0;
+        int r = -1, pt = 0, direct = 0; uint64_t lu = 0, ll = 0; int32_t xl = 0; int xb = 0; int64_t doff = 0;
         if (e < nE) {
             pt = e < nU ? e : (e == nU ? pividx : e - 1);
             r = ent_row(pt); xl = ent_len(pt); xb = ent_bits(pt);
-            if (e < nUe) lu = (uint64_t) slip_limbs(xl); else ll = (uint64_t) slip_limbs(xl);
+            if (e < nUe) lu = (uint64_t) slip_limbs(xl);
+            else {
+                if (use_tab) { direct = (int)(tab[4 * pt + 3] >> 31); doff = Lnl + (int64_t)(tab[4 * pt + 3] & 0x7FFFFFFFu); }
+                else if (P.xrow[r].pad) { direct = 1; doff = *(const int64_t *)(P.xd + (int64_t) r * P.xcap); }
+                if (!direct) ll = (uint64_t) slip_limbs(xl);
+                else lu = (uint64_t) slip_limbs(xl) << 32;             /* summed in the high half of the U channel */
+            }
         }
         uint64_t eu, el, tu, tl;
         slip_block_scan2(lu, ll, scan_tmp, &eu, &el, &tu, &tl);
@@ -1213,37 +1247,42 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             /* capacity is verified before anything is committed; these records are provisional */
             if (e < nUe) {
                 const int64_t at = Unz + e;
-                if (at < P.Ucap_nz) { P.Ui[at] = r; SlipEnt en; en.off = Unl + (int64_t)(baseU + eu); en.len = xl; en.bits = xb; P.Ue[at] = en; }
+                if (at < P.Ucap_nz) { P.Ui[at] = r; SlipEnt en; en.off = Unl + (int64_t)(baseU + (eu & 0xFFFFFFFFull)); en.len = xl; en.bits = xb; P.Ue[at] = en; }
             } else {
                 const int64_t at = Lnz + (e - nUe);
-                if (at < P.Lcap_nz) { P.Li[at] = r; SlipEnt en; en.off = Lnl + (int64_t)(baseL + el); en.len = xl; en.bits = xb; P.Le[at] = en; }
-                if (use_tab) tab[4 * pt + 3] = (uint32_t)(baseL + el);      /* L slab offset relative to Lnl */
+                const int64_t off = direct ? doff : Lnl + (int64_t)(lalloc + baseL + el);
+                if (at < P.Lcap_nz) { P.Li[at] = r; SlipEnt en; en.len = xl; en.bits = xb; en.off = off; P.Le[at] = en; }
+                if (use_tab && !direct) tab[4 * pt + 3] = (uint32_t)(off - Lnl);     /* copy destination, flag bit clear */
             }
         }
-        baseU += tu; baseL += tl;
+        baseU += tu & 0xFFFFFFFFull; dirL += tu >> 32; baseL += tl;
     }
-    const uint64_t totU = baseU, totL = baseL;
+    const uint64_t totU = baseU, totL = lalloc + baseL;         /* limbs of slab consumed by this column */
+    const uint64_t totLexact = baseL + dirL;
     if (Unz + nUe > P.Ucap_nz || Unl + (int64_t) totU > P.Ucap_nl) return SLIPDEV_GROW_U;
     if (Lnz + nL > P.Lcap_nz || Lnl + (int64_t) totL > P.Lcap_nl) return SLIPDEV_GROW_L;
     slip_block_sync();
     SLIP_STAMP(5);
     /* limbs: one wave per entry, coalesced; x rows are stored padded to whole limbs and nobody reads
-     * the slabs before the barrier below */
+     * the slabs before the barrier below.  Rows that already live in the L slab are not copied. */
     for (int e = wave; e < nE; e += nw) {
         const int isU = e < nUe;
-        int r; int32_t xl; dig_t *dst;
+        const dig_t *srcx; dig_t *dst; int32_t xl;
         if (use_tab && !isU) {
             const int pt = e - 1;
-            r = (int) tab[4 * pt]; xl = (int32_t) tab[4 * pt + 1];
+            if (tab[4 * pt + 3] >> 31) continue;                 /* multiplied straight into the slab */
+            xl = (int32_t) tab[4 * pt + 1];
+            srcx = P.xd + (int64_t) tab[4 * pt] * P.xcap;
             dst = (dig_t *)(P.Llimbs + Lnl + (int64_t) tab[4 * pt + 3]);
         } else {
             const int64_t at = isU ? Unz + e : Lnz + (e - nUe);
-            r = isU ? P.Ui[at] : P.Li[at];
+            const int r = isU ? P.Ui[at] : P.Li[at];
             const SlipEnt en = isU ? P.Ue[at] : P.Le[at];
             xl = en.len;
+            srcx = row_digits(r);
             dst = isU ? (dig_t *)(P.Ulimbs + en.off) : (dig_t *)(P.Llimbs + en.off);
+            if (dst == srcx) continue;
         }
-        const dig_t *srcx = P.xd + (int64_t) r * P.xcap;
         const int lw = (slip_abs(xl) + 1) & ~1;
         for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = srcx[c];
     }
@@ -1267,8 +1306,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             P.pinv[pivrow] = k; P.pinv[intermed2] = intermed;
             sv64[SV_UNZ / 2] = Unz + nUe; sv64[SV_UNL / 2] = Unl + (int64_t) totU;
             sv64[SV_LNZ / 2] = Lnz + nL;  sv64[SV_LNL / 2] = Lnl + (int64_t) totL;
+            sv64[SV_LNLX / 2] = sv64[SV_LNLX / 2] + (int64_t) totLexact;
             P.Up[k + 1] = Unz + nUe; P.Lp[k + 1] = Lnz + nL;
-            st->c_write += 4ull * (unsigned long long) nE + 8ull * (totU + totL) + 8ull * slip_limbs(pe.len);
+            st->c_write += 4ull * (unsigned long long) nE + 8ull * (totU + totLexact) + 8ull * slip_limbs(pe.len);
             if ((unsigned long long) maxdig > st->c_maxdig) st->c_maxdig = (unsigned long long) maxdig;
         }
     }
@@ -1279,9 +1319,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
 }
 
 /* the kernel body: columns [k_next, k_stop) on ONE workgroup */
-template <bool BM_LDS, bool SCR_LDS>
+template <bool FAST>
 SLIP_DEV void slip_factor_columns(const SlipParams &P, SlipState *st, uint32_t *lds)
 {
+    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
     if (slip_block() != 0) {
         const int wcap = P.wcap, wave = slip_wave();
         dig_t *hb0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
@@ -1296,11 +1337,12 @@ SLIP_DEV void slip_factor_columns(const SlipParams &P, SlipState *st, uint32_t *
     int k = st->k_next;
     if (slip_tid() == 0) {
         sv64[SV_LNZ / 2] = st->Lnz; sv64[SV_LNL / 2] = st->Lnl; sv64[SV_UNZ / 2] = st->Unz; sv64[SV_UNL / 2] = st->Unl;
+        sv64[SV_LNLX / 2] = st->Lnl_exact;
     }
     int status = SLIPDEV_OK;
     slip_block_sync();
     for (; k < P.k_stop; k++) {
-        status = slip_do_column<BM_LDS, SCR_LDS>(P, st, k, lds, &t_read, &t_upd, &t_src, &t_str);
+        status = slip_do_column<FAST>(P, st, k, lds, &t_read, &t_upd, &t_src, &t_str);
         if (status != SLIPDEV_OK) break;
     }
     slip_block_sync();
@@ -1319,6 +1361,7 @@ SLIP_DEV void slip_factor_columns(const SlipParams &P, SlipState *st, uint32_t *
     if (slip_tid() == 0) {
         st->c_read += a; st->c_upd += b; st->c_src += c; st->c_streamed += d;
         st->Lnz = sv64[SV_LNZ / 2]; st->Lnl = sv64[SV_LNL / 2]; st->Unz = sv64[SV_UNZ / 2]; st->Unl = sv64[SV_UNL / 2];
+        st->Lnl_exact = sv64[SV_LNLX / 2];
         st->k_next = k; st->status = status; st->status_k = k; st->seq = sv[SV_GEN];
     }
 }

@@ -69,12 +69,12 @@ SLIP_DEV void slip_reg_op_test(int op, const uint32_t *A, int la, const uint32_t
 
 #ifndef SLIP_EMULATE
 #define SLIP_MAX_WAVES 8                   /* 512 threads: 2 waves per SIMD, 256 VGPRs per lane */
-template <bool BM_LDS, bool SCR_LDS>
+template <bool FAST>
 __global__ void __launch_bounds__(64 * SLIP_MAX_WAVES)
 slip_factor_kernel(SlipParams P, SlipState *st)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t slip_lds[];
-    slip_factor_columns<BM_LDS, SCR_LDS>(P, st, slip_lds);      /* block 0: column loop; blocks >= 1: helpers */
+    slip_factor_columns<FAST>(P, st, slip_lds);      /* block 0: column loop; blocks >= 1: helpers */
 }
 
 /* unit-test kernel: block b performs operation b with one wavefront */
@@ -399,23 +399,21 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;
     const dim3 grid(1 + f->P.nhelpers), block(64 * f->waves);
-#define SLIP_LAUNCH(BM, SC) do { \
-        CK(hipFuncSetAttribute((const void *) slip_factor_kernel<BM, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes)); \
-        hipLaunchKernelGGL((slip_factor_kernel<BM, SC>), grid, block, lds_bytes, stream, f->P, f->ds); } while (0)
-    if (f->bitmap_in_lds && f->scratch_in_lds) SLIP_LAUNCH(true, true);
-    else if (f->bitmap_in_lds) SLIP_LAUNCH(true, false);
-    else if (f->scratch_in_lds) SLIP_LAUNCH(false, true);
-    else SLIP_LAUNCH(false, false);
+    f->P.bitmap_in_lds = f->bitmap_in_lds; f->P.scratch_in_lds = f->scratch_in_lds;
+#define SLIP_LAUNCH(FAST) do { \
+        CK(hipFuncSetAttribute((const void *) slip_factor_kernel<FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes)); \
+        hipLaunchKernelGGL((slip_factor_kernel<FAST>), grid, block, lds_bytes, stream, f->P, f->ds); } while (0)
+    if (f->bitmap_in_lds && f->scratch_in_lds) SLIP_LAUNCH(true);
+    else SLIP_LAUNCH(false);
 #undef SLIP_LAUNCH
     CK(hipGetLastError());
 #else
+    f->P.bitmap_in_lds = f->bitmap_in_lds; f->P.scratch_in_lds = f->scratch_in_lds;
     const SlipParams P = f->P; SlipState *ds = f->ds;
-    const int bm = f->bitmap_in_lds, sc = f->scratch_in_lds;
-    emu::launch(1, 64 * f->waves, [P, ds, bm, sc]() {
-        if (bm && sc) slip_factor_columns<true, true>(P, ds, slip_emu_lds);
-        else if (bm) slip_factor_columns<true, false>(P, ds, slip_emu_lds);
-        else if (sc) slip_factor_columns<false, true>(P, ds, slip_emu_lds);
-        else slip_factor_columns<false, false>(P, ds, slip_emu_lds);
+    const int fast = f->bitmap_in_lds && f->scratch_in_lds;
+    emu::launch(1, 64 * f->waves, [P, ds, fast]() {
+        if (fast) slip_factor_columns<true>(P, ds, slip_emu_lds);
+        else slip_factor_columns<false>(P, ds, slip_emu_lds);
     });
 #endif
     CK(hipEventRecord(f->ev1, stream));
@@ -506,7 +504,7 @@ extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)
     if (!f || !o) return SLIP_HIP_INCORRECT_INPUT;
     const SlipState *h = &f->hs;
     o->n = f->n; o->K = h->k_next; o->status = f->last_status; o->window_end = f->window_end;
-    o->lnz = h->Lnz; o->unz = h->Unz; o->l_limbs = h->Lnl; o->u_limbs = h->Unl;
+    o->lnz = h->Lnz; o->unz = h->Unz; o->l_limbs = h->Lnl_exact; o->u_limbs = h->Unl;
     o->n_upd = (int64_t) h->c_upd; o->b_read = (int64_t) h->c_read; o->b_write = (int64_t) h->c_write;
     o->n_src = (int64_t) h->c_src; o->l_streamed = (int64_t) h->c_streamed;
     o->max_limbs = (int64_t)((h->c_maxdig + 1) / 2);
@@ -547,7 +545,23 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
     if (Ui && h->Unz) CK(hipMemcpy(Ui, P->Ui, (size_t) h->Unz * 4, hipMemcpyDeviceToHost));
     if (Llen && (e = fetch_lens(Llen, P->Le, h->Lnz))) return e;
     if (Ulen && (e = fetch_lens(Ulen, P->Ue, h->Unz))) return e;
-    if (Llimbs && h->Lnl) CK(hipMemcpy(Llimbs, P->Llimbs, (size_t) h->Lnl * 8, hipMemcpyDeviceToHost));
+    if (Llimbs && h->Lnl) {
+        /* rows multiplied straight into the slab may leave one unused limb behind them: the slab is
+         * gathered entry by entry into the back-to-back layout of the ABI */
+        SlipEnt *le = (SlipEnt *) malloc((size_t)(h->Lnz ? h->Lnz : 1) * sizeof(SlipEnt));
+        uint64_t *raw = (uint64_t *) malloc((size_t) h->Lnl * 8);
+        if (!le || !raw) { free(le); free(raw); return SLIP_HIP_OUT_OF_MEMORY; }
+        if (hipMemcpy(le, P->Le, (size_t) h->Lnz * sizeof(SlipEnt), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(raw, P->Llimbs, (size_t) h->Lnl * 8, hipMemcpyDeviceToHost) != hipSuccess) { free(le); free(raw); return SLIP_HIP_DEVICE_ERROR; }
+        int64_t o = 0;
+        for (int64_t t = 0; t < h->Lnz; t++) {
+            const int32_t d = le[t].len;
+            const int64_t l = ((d < 0 ? -d : d) + 1) >> 1;
+            memcpy(Llimbs + o, raw + le[t].off, (size_t) l * 8);
+            o += l;
+        }
+        free(le); free(raw);
+    }
     if (Ulimbs && h->Unl) CK(hipMemcpy(Ulimbs, P->Ulimbs, (size_t) h->Unl * 8, hipMemcpyDeviceToHost));
     if (pinv) CK(hipMemcpy(pinv, P->pinv, (size_t) f->n * 4, hipMemcpyDeviceToHost));
     if ((rholen || rholimbs) && K > 0) {
