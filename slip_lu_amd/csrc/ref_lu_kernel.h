@@ -356,8 +356,11 @@ template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, 
     return slip_store_x_reg<D>(P, r, Y, sign, xr.h);
 }
 
+/* fuse_k >= 0: row i is non-pivotal and this is the column's last source, so the history update to level
+ * fuse_k-1 (x * rho[fuse_k-1] / rho[jn], slip_REF_triangular_solve.c:248-257) is applied in the same pass;
+ * Wf = digits of that result. */
 template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int j, int jn, int64_t m, dig_t *b0,
-                                                 int W, int W1, int hist, int hdiv, int mode, int publish)
+                                                 int W, int W1, int hist, int hdiv, int mode, int publish, int fuse_k, int Wf)
 {
     const SlipRow xi = P.xrow[i], xj = P.xrow[j];
     const SlipEnt le = P.Le[m];
@@ -368,6 +371,7 @@ template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int
     if (has_d) Dv = P.piv[jn - 1];
     if (hdiv) { const int e = slip_ensure_inv_reg<D>(P, xi.h, W1, b0, publish); if (e) return e; }
     if (has_d) { const int e = slip_ensure_inv_reg<D>(P, jn - 1, W, b0, publish); if (e) return e; }
+    if (fuse_k >= 0) { const int e = slip_ensure_inv_reg<D>(P, jn, Wf, b0, publish); if (e) return e; }
     if (mode == 1) return 0;
     const int CAP = 64 * D;
     const int lr = slip_abs(R.len) < W1 ? slip_abs(R.len) : W1;
@@ -415,6 +419,19 @@ template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int
         sT *= slip_sgn(Dv.len);
     }
     if (wr_digit<D>(T, W - 1) >> 31) { T = wr_mask<D>(wr_addsub<D>(wr_zero<D>(), T, 1), W); sT = -sT; }
+    if (fuse_k >= 0) {
+        const int lt = wr_len<D>(T);
+        if (lt > 0) {
+            const SlipPiv Mk = P.piv[fuse_k - 1];
+            const int lmk = slip_abs(Mk.len) < CAP ? slip_abs(Mk.len) : CAP;
+            WR<D> Mr = wr_load<D>(slip_piv_digits(P, Mk), lmk);
+            WR<D> Y = lt <= lmk ? wr_mul<D>(T, lt, Mr) : wr_mul<D>(Mr, lmk, T);
+            Y = wr_mask<D>(wr_shr<D>(Y, R.ctz, b0), Wf);
+            WR<D> IR = wr_load<D>(P.invd + (int64_t) jn * P.invcap, Wf);
+            Y = wr_mask<D>(wr_mul<D>(IR, Wf, Y), Wf);
+            return slip_store_x_reg<D>(P, i, Y, sT * slip_sgn(Mk.len) * slip_sgn(R.len), fuse_k - 1);
+        }
+    }
     return slip_store_x_reg<D>(P, i, T, sT, jn);
 }
 
@@ -464,7 +481,7 @@ SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t
  * (pivot position jn) through the L entry m, one wavefront, everything modulo B^W:
  *     x[i] <- ( hist(x[i]) * rho[jn] - L_m * x[j] ) / rho[jn-1]                          */
 SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m, dig_t *b0, dig_t *b1, dig_t *b2,
-                            int mode = 0, int publish = 1)
+                            int mode = 0, int publish = 1, int fuse_k = -1)
 {
     const SlipRow xi = P.xrow[i], xj = P.xrow[j];
     const SlipEnt le = P.Le[m];
@@ -495,11 +512,19 @@ SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m
     const int W1 = W + (has_d ? ((zd + 31) >> 5) : 0);
     const int W2 = W1 + (hdiv ? ((zh + 31) >> 5) : 0);
     if (W2 > P.wcap) return 1;
+    /* last source of the column and a non-pivotal row: fold the history update to level fuse_k-1 in */
+    int fk = -1, Wf = 0, Wall = W2;
+    if (fuse_k >= 1 && jn < fuse_k - 1 && P.pinv[i] >= fuse_k) {
+        const int bf = bq + P.piv[fuse_k - 1].bits - br + 1;
+        Wf = (bf + 31) >> 5; if (Wf < 1) Wf = 1;
+        const int need = Wf + ((R.ctz + 31) >> 5);
+        if (need <= 256 && W2 <= 256 && Wf <= P.xcap && Wf <= P.invcap) { fk = fuse_k; if (need > Wall) Wall = need; }
+    }
     /* operands that fit 256 digits stay in registers */
-    if (W2 <= 64)  return slip_ipge_wave_reg<1>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish);
-    if (W2 <= 128) return slip_ipge_wave_reg<2>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish);
-    if (W2 <= 192) return slip_ipge_wave_reg<3>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish);
-    if (W2 <= 256) return slip_ipge_wave_reg<4>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish);
+    if (Wall <= 64)  return slip_ipge_wave_reg<1>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish, fk, Wf);
+    if (Wall <= 128) return slip_ipge_wave_reg<2>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish, fk, Wf);
+    if (Wall <= 192) return slip_ipge_wave_reg<3>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish, fk, Wf);
+    if (Wall <= 256) return slip_ipge_wave_reg<4>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish, fk, Wf);
     if (hdiv) { const int e = slip_ensure_inv(P, hi, W1, b0, b1, b2, publish); if (e) return e; }
     if (has_d) { const int e = slip_ensure_inv(P, jn - 1, W, b0, b1, b2, publish); if (e) return e; }
     if (mode == 1) return 0;
@@ -623,10 +648,11 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
 #define SLIP_SPIN_LIMIT 30000000ull            /* ~30 s: the master gives up on helpers that do not answer   */
 #define SLIP_IDLE_LIMIT 1000000000ull          /* ~15 min: helpers idle for as long as the column loop runs */
 
+/* kind 1: k is the fuse level (-1: none) of the IPGE updates; kind 2: k is the column of the history rows */
 SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, int64_t m0, const uint32_t *items, int t,
                            dig_t *b0, dig_t *b1, dig_t *b2, int mode, int publish)
 {
-    if (kind == 1) return slip_ipge_wave(P, (int) items[2 * t + 1], j, jn, m0 + (int64_t) items[2 * t], b0, b1, b2, mode, publish);
+    if (kind == 1) return slip_ipge_wave(P, (int) items[2 * t + 1], j, jn, m0 + (int64_t) items[2 * t], b0, b1, b2, mode, publish, k);
     const int r = (int) items[t];
     return slip_history_wave(P, r, k - 1, P.xrow[r].h, b0, b1, b2, mode, publish);
 }
@@ -838,12 +864,14 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             /* queued multi-limb updates of the previous source: one wavefront each */
             const int nq = sv[SV_CNT0 + (step + 2) % 3];
             if (tid == 0) sv[SV_CNT0 + (step + 1) % 3] = 0;
+            /* the bitmap is complete for the previous source, so the next one is already known; if there is
+             * none, the queued updates of non-pivotal rows fold their history update to level k-1 in */
+            const int jn = slip_bitmap_next(bm, cur + 1, k);
             if (nq > 0) {
                 slip_block_sync();
-                slip_drain(P, lds, 1, pj, pjn, k, P.Lp[pjn], nq, work + ((step + 1) & 1) * 2 * SLIP_WORK_CAP, b0, b1, b2);
+                slip_drain(P, lds, 1, pj, pjn, jn < 0 ? k : -1, P.Lp[pjn], nq, work + ((step + 1) & 1) * 2 * SLIP_WORK_CAP, b0, b1, b2);
                 if (sv[SV_ERR]) break;
             }
-            const int jn = slip_bitmap_next(bm, cur + 1, k);
             if (jn < 0) break;
             cur = jn;
             const int j = P.row_perm[jn];
@@ -890,7 +918,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                         slip_block_sync();
                     }
                     const int nq2 = *wcnt;
-                    slip_drain(P, lds, 1, j, jn, k, m0, nq2, wl, b0, b1, b2);
+                    slip_drain(P, lds, 1, j, jn, -1, m0, nq2, wl, b0, b1, b2);
                     if (tid == 0) *wcnt = 0;
                     slip_block_sync();
                 }
