@@ -18,6 +18,9 @@
  *          more than `cap` 64-bit limbs (cap <= 0: no cap); counts the
  *          algorithmic bytes while doing so.
  *   order  <input> <out.slab> [order]             only the column ordering q
+ *   solve  <input> <out.slab> [pivot order tol]   full factorisation, then SLIP_LU_solve on the deterministic
+ *          right-hand side b_i = ((i*2654435761) mod 2001) - 1000 (one column); dumps the rational solution
+ *          (before SLIP_permute_x) as numerator / denominator limb lists "xnum*", "xden*"
  * <input> is  trip:<path>  (the reference's triplet text, Demo/demos.c:245-331)
  *         or  gen:<n>,<density>,<bits>,<seed>     (slip_matgen.h)
  * Optional trailing argument  q:<file.slab>  takes q from a slab file instead
@@ -157,7 +160,7 @@ int main(int argc, char **argv)
     SLIP_sparse *A = read_input(argv[2]);
     int32_t n = A->n;
     SLIP_options *opt = SLIP_create_default_options();
-    int is_window = !strcmp(mode, "window"), is_order = !strcmp(mode, "order");
+    int is_window = !strcmp(mode, "window"), is_order = !strcmp(mode, "order"), is_solve = !strcmp(mode, "solve");
     int32_t K = n, cap = 0;
     int ai = 4;
     if (is_window) { if (argc < 6) DIE("window needs K cap"); K = atoi(argv[4]); cap = atoi(argv[5]); ai = 6; }
@@ -272,6 +275,23 @@ int main(int argc, char **argv)
         for (int32_t k = 0; k < Kdone; k++) flat_push(&fr, rhos[k]);
         slab_put(out, "rholen", SLAB_I32, fr.len, fr.n);
         slab_put(out, "rholimbs", SLAB_U64, fr.limbs, fr.nl);
+    }
+    if (is_solve && ok == SLIP_OK) {
+        /* SLIP_LU_solve (SLIP_LU_solve.c:41-86) wants the relabelled factors SLIP_LU_factorize returned */
+        SLIP_dense *b = SLIP_create_dense();
+        mpz_t **bm = SLIP_create_mpz_mat(n, 1);
+        for (int32_t i = 0; i < n; i++) mpz_set_si(bm[i][0], (long)(((unsigned) i * 2654435761u) % 2001u) - 1000);
+        if (SLIP_build_dense_mpz(b, bm, n, 1) != SLIP_OK) DIE("build b");
+        mpq_t **x = SLIP_create_mpq_mat(n, 1);
+        double ts = now_s();
+        SLIP_info sok = SLIP_LU_solve(x, b, rhos, L, U, pinv);
+        ts = now_s() - ts;
+        if (sok != SLIP_OK) DIE("SLIP_LU_solve returned %d", (int) sok);
+        flat_t fn, fd; flat_init(&fn, n); flat_init(&fd, n);
+        for (int32_t i = 0; i < n; i++) { flat_push(&fn, mpq_numref(x[i][0])); flat_push(&fd, mpq_denref(x[i][0])); }
+        slab_put(out, "xnumlen", SLAB_I32, fn.len, fn.n); slab_put(out, "xnumlimbs", SLAB_U64, fn.limbs, fn.nl);
+        slab_put(out, "xdenlen", SLAB_I32, fd.len, fd.n); slab_put(out, "xdenlimbs", SLAB_U64, fd.limbs, fd.nl);
+        slab_put(out, "solve_seconds", SLAB_F64, &ts, 1);
     }
     slab_put(out, "counters", SLAB_I64, counters, 8);
     double tm[2] = { t_factor, t_sym };

@@ -107,7 +107,36 @@ def run_case(name):
         return entry
 
 
+# rational solutions of SLIP_LU_solve for the deterministic right-hand side of ref_driver's `solve` mode
+SOLVE_CASES = {
+    "solve_test_mat": f"trip:{REF}/test_mat.txt",
+    "solve_10teams":  f"trip:{REF}/10teams_mat.txt",
+    "solve_gen_n40":  "gen:40,0.15,8,5",
+}
+
+
+def run_solve_cases():
+    idx = []
+    with tempfile.TemporaryDirectory() as td:
+        for name, spec in SOLVE_CASES.items():
+            out = os.path.join(td, "s.slab")
+            subprocess.check_call([DRIVER, "solve", spec, out], stderr=subprocess.DEVNULL)
+            d = slabfile.load(out)
+            fix = {k: d[k] for k in ("q", "pinv", "xnumlen", "xnumlimbs", "xdenlen", "xdenlimbs")}
+            if not spec.startswith("gen:"):
+                subprocess.check_call([DRIVER, "order", spec, os.path.join(td, "a.slab")], stderr=subprocess.DEVNULL)
+                a = slabfile.load(os.path.join(td, "a.slab"))
+                for k in ("Ap", "Ai", "Alen", "Alimbs"):
+                    fix[k] = a[k]
+            slabfile.save(os.path.join(HERE, name + ".slab.gz"), fix)
+            idx.append(dict(name=name, input=spec if spec.startswith("gen:") else "slab", n=int(d["n"][0])))
+    json.dump(idx, open(os.path.join(HERE, "solve_index.json"), "w"), indent=1)
+
+
 def main():
+    if sys.argv[1:] == ["solve"]:
+        run_solve_cases()
+        return
     names = sys.argv[1:] or list(CASES)
     idx_path = os.path.join(HERE, "index.json")
     index = {}

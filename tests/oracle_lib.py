@@ -45,6 +45,48 @@ def lib():
     return _lib
 
 
+def solve_rhs(n):
+    """the deterministic right-hand side of the solve goldens (oracle/ref_driver.c, mode solve)"""
+    return np.array([((i * 2654435761) % (1 << 32)) % 2001 - 1000 for i in range(n)], dtype=np.int64)
+
+
+def factorize_and_solve(n, Ap, Ai, Alen, Alimbs, q, b, pivot=3, tol=1.0):
+    """orc_factorize + orc_solve: returns (numerators as python ints in permuted order, det as python int)."""
+    Ap = np.ascontiguousarray(Ap, dtype=np.int64); Ai = np.ascontiguousarray(Ai, dtype=np.int32)
+    Alen = np.ascontiguousarray(Alen, dtype=np.int32); Alimbs = np.ascontiguousarray(Alimbs, dtype=np.uint64)
+    q = np.ascontiguousarray(q, dtype=np.int32)
+    L = lib()
+    r = L.orc_factorize(n, Ap.ctypes.data, Ai.ctypes.data, Alen.ctypes.data, Alimbs.ctypes.data, q.ctypes.data,
+                        pivot, float(tol), 0, 0)
+    assert r and r.contents.status == 0 and r.contents.K == n
+    b = np.asarray(b, dtype=np.int64)
+    blen = np.sign(b).astype(np.int32); blimbs = np.abs(b[b != 0]).astype(np.uint64)
+    if blimbs.size == 0:
+        blimbs = np.zeros(1, np.uint64)
+    xl, xp, nl = C.POINTER(C.c_int32)(), C.POINTER(C.c_uint64)(), C.c_int64()
+    L.orc_solve.argtypes = [C.POINTER(_Result), C.c_int32, C.c_void_p, C.c_void_p,
+                            C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int64)]
+    rc = L.orc_solve(r, 1, blen.ctypes.data, blimbs.ctypes.data, C.byref(xl), C.byref(xp), C.byref(nl))
+    assert rc == 0
+    lens = _arr(xl, n, np.int32); limbs = _arr(xp, nl.value, np.uint64)
+    R = r.contents
+    rl = _arr(R.rholen, n, np.int32); rlimbs = _arr(R.rholimbs, R.rhonl, np.uint64)
+    L.orc_free_ptr(C.cast(xl, C.c_void_p)); L.orc_free_ptr(C.cast(xp, C.c_void_p))
+    L.orc_free(r)
+    return bigints(lens, limbs), bigints(rl, rlimbs)[-1]
+
+
+def bigints(lens, limbs):
+    """(signed limb counts, limbs) -> list of python ints"""
+    out, o = [], 0
+    for l in lens:
+        a = abs(int(l)); v = 0
+        for t in range(a):
+            v |= int(limbs[o + t]) << (64 * t)
+        out.append(-v if l < 0 else v); o += a
+    return out
+
+
 def _arr(ptr, count, dtype):
     if count <= 0:
         return np.zeros(0, dtype=dtype)
