@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="only the headline workload (used under rocprofv3 so that the kernel statistics are the headline's)")
     args = ap.parse_args()
 
     import numpy as np
@@ -137,7 +139,7 @@ def main():
 
     # secondary, complete-run workloads (LP bases / ExampleMats of the reference): one run each
     secondary = []
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_secondary:
         from conftest import load_case
         for name in ("10teams", "prob159", "NSR8K_w600", "rl5934"):
             try:
