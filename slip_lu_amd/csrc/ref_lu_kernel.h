@@ -92,12 +92,21 @@ typedef struct SlipBatch {
     int32_t stale_seen, pad4[23];                   /* diagnostics: payload re-reads a helper needed */
 } SlipBatch;
 
+/* arguments of the REF triangular solves (SLIP_LU_solve.c:41-86) on resident factors */
+typedef struct SlipSolveArgs {
+    int32_t nrhs, pad;
+    const int32_t *blen; const int64_t *boff; const uint64_t *blimbs;   /* dense b, entry (c,i) at c*n+i: signed digits, limb offset */
+    int32_t *olen; int64_t *ooff; uint64_t *olimbs; int64_t ocap;       /* numerators over det = rho[n-1], by pivot position        */
+} SlipSolveArgs;
+
 /* mutable across launches */
 typedef struct SlipState {
     int32_t k_next, status, status_k;
     int32_t seq;                                    /* batch generation: monotonic across launches */
     int64_t Lnz, Lnl, Unz, Unl;                     /* Lnl counts allocated limbs (a direct row may leave one limb unused) */
-    int64_t Lnl_exact, pad64;                       /* limbs actually stored in L                                          */
+    int64_t Lnl_exact;                              /* limbs actually stored in L                                          */
+    int64_t out_used;                               /* solve: limbs of the output slab in use                              */
+    int32_t solve_next, pad32;                      /* solve: next right-hand side                                         */
     unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig;
     unsigned long long prof[12];                    /* -DSLIP_PROFILE_PHASES builds only */
 } SlipState;
@@ -648,12 +657,51 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
 #define SLIP_SPIN_LIMIT 30000000ull            /* ~30 s: the master gives up on helpers that do not answer   */
 #define SLIP_IDLE_LIMIT 1000000000ull          /* ~15 min: helpers idle for as long as the column loop runs */
 
+/* ---- REF triangular solves (SLIP_LU_solve.c:41-86): the two extra wave-level operations ---- */
+
+/* x[r] <- x[r] / rho[p], exact (slip_back_sub.c:43: divide by the diagonal of U = the pivot) */
+SLIP_DEV int slip_divexact_wave(const SlipParams &P, int r, int p, dig_t *b0, dig_t *b1, dig_t *b2, int mode, int publish)
+{
+    const SlipRow xr = P.xrow[r];
+    const int lx = slip_abs(xr.len);
+    const SlipPiv d = P.piv[p];
+    const int bq = xr.bits - d.bits + 1;
+    const int W = bq > 0 ? (bq + 31) >> 5 : 1, zh = d.ctz, W2 = W + ((zh + 31) >> 5);
+    if (W2 > P.wcap) return 1;
+    { const int e = slip_ensure_inv(P, p, W, b0, b1, b2, publish); if (e) return e; }
+    if (mode == 1) return 0;
+    wb_copy_shr(b1, P.xd + (int64_t) r * P.xcap, lx, zh, W);
+    wb_mul_lo(b2, b1, W, P.invd + (int64_t) p * P.invcap, W, W);
+    return slip_store_x(P, r, b2, W, slip_sgn(xr.len) * slip_sgn(d.len), xr.h);
+}
+
+/* x[i] <- x[i] - U_m * x[j]   (slip_back_sub.c:44-50) */
+SLIP_DEV int slip_submul_wave(const SlipParams &P, int i, int j, int64_t m, dig_t *b0, dig_t *b1, dig_t *b2, int mode)
+{
+    if (mode == 1) return 0;
+    const SlipRow xi = P.xrow[i], xj = P.xrow[j];
+    const SlipEnt ue = P.Ue[m];
+    const int lx = slip_abs(xi.len), sx = slip_sgn(xi.len);
+    const int bt = (xi.bits > ue.bits + xj.bits ? xi.bits : ue.bits + xj.bits) + 1;
+    const int W = (bt + 1 + 31) >> 5;                       /* + sign bit */
+    if (W > P.wcap) return 1;
+    wb_mul_lo(b2, (const dig_t *)(P.Ulimbs + ue.off), slip_abs(ue.len), P.xd + (int64_t) j * P.xcap, slip_abs(xj.len), W);
+    const int s2 = slip_sgn(ue.len) * slip_sgn(xj.len);
+    if (lx == 0) return slip_store_x(P, i, b2, W, -s2, xi.h);
+    int sT = sx;
+    wb_addsub(b1, P.xd + (int64_t) i * P.xcap, lx, b2, W, W, sx == s2);       /* |x| -/+ |U x_j| */
+    if (sx == s2 && (b1[W - 1] >> 31)) { wb_addsub(b1, (const dig_t *) 0, 0, b1, W, W, 1, 0u); sT = -sT; }
+    return slip_store_x(P, i, b1, W, sT, xi.h);
+}
+
 /* kind 1: k is the fuse level (-1: none) of the IPGE updates; kind 2: k is the column of the history rows */
 SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, int64_t m0, const uint32_t *items, int t,
                            dig_t *b0, dig_t *b1, dig_t *b2, int mode, int publish)
 {
     if (kind == 1) return slip_ipge_wave(P, (int) items[2 * t + 1], j, jn, m0 + (int64_t) items[2 * t], b0, b1, b2, mode, publish, k);
+    if (kind == 5) return slip_submul_wave(P, (int) items[2 * t + 1], j, m0 + (int64_t) items[2 * t], b0, b1, b2, mode);
     const int r = (int) items[t];
+    if (kind == 4) return slip_history_wave(P, r, k - 1, -1, b0, b1, b2, mode, publish);      /* x * rho[k-1] */
     return slip_history_wave(P, r, k - 1, P.xrow[r].h, b0, b1, b2, mode, publish);
 }
 
@@ -678,7 +726,7 @@ SLIP_DEV int slip_drain_begin(const SlipParams &P, uint32_t *lds, int kind, int 
     if (sv[SV_ERR]) return 0;                 /* _end will see the error and do nothing */
     /* 2. publish: items and descriptor to HBM, agent-scope release, bump the generation */
     SlipBatch *B = P.batch;
-    const int nwords = kind == 1 ? 2 * nq : nq;
+    const int nwords = (kind == 1 || kind == 5) ? 2 * nq : nq;
     for (int t = tid; t < nwords; t += T) P.batch_items[t] = wl[t];
     if (tid == 0) {
         B->kind = kind; B->nitems = nq; B->j = j; B->jn = jn; B->k = k; B->m0 = m0; B->stamp = sv[SV_GEN] + 1;
@@ -799,60 +847,18 @@ SLIP_DEV void slip_helper_loop(const SlipParams &P, const SlipState *st, uint32_
 }
 
 /* ------------------------------------------------------------------ */
-/* one column; returns a SLIPDEV_* status (0 = committed)              */
-/* ------------------------------------------------------------------ */
-/* FAST: bitmap and wave scratch both in LDS (addresses provably LDS, ds_* instructions);
- * otherwise the generic build picks either place at run time (flat addressing). */
+/* The ascending sweep over the pivotal positions < k of the pattern (slip_REF_triangular_solve.c:124-241):
+ * the bitmap already holds the scattered rows.  Used for a column of the factorisation (k = column)
+ * and, with k = n and the right-hand side scattered instead of A(:,col), as the REF forward
+ * substitution (slip_forward_sub.c:61-158 is the same recurrence over all positions).
+ * Called by all threads; the caller syncs and checks sv[SV_ERR] afterwards. */
 template <bool FAST>
-SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uint32_t *lds,
-                            unsigned long long *t_read, unsigned long long *t_upd,
-                            unsigned long long *t_src, unsigned long long *t_str)
+SLIP_DEV void slip_sweep(const SlipParams &P, const int k, uint32_t *lds, uint32_t *bm, dig_t *b0, dig_t *b1, dig_t *b2,
+                         unsigned long long &c_read, unsigned long long &c_upd, unsigned long long &c_src, unsigned long long &c_str)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
-    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
-    const int col = P.q[k];
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
-    volatile int64_t *sv64 = (volatile int64_t *)(lds + SLIP_LDS_VARS);
-    uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
     uint32_t *work = lds + SLIP_LDS_WORK;
-    uint32_t *bm = BM_LDS ? lds + SLIP_LDS_BITMAP : P.gbitmap;
-    const int wcap = P.wcap;
-    dig_t *b0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
-                        : P.gscratch + (int64_t) wave * 3 * wcap;
-    dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
-    unsigned long long c_read = 0, c_upd = 0, c_src = 0, c_str = 0;
-    SLIP_STAMP_INIT();
-
-    /* ---- phase 0: clear the pattern bitmap ---- */
-    for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
-    if (tid == 0) { sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv64[SV_LALLOC / 2] = 0; sv64[SV_LEXACT / 2] = 0; }
-    slip_block_sync();
-
-    /* ---- phase 1: scatter A(:,col) into x (slip_REF_triangular_solve.c:105-119) ---- */
-    for (int64_t p = P.Ap[col] + tid; p < P.Ap[col + 1]; p += T) {
-        const int row = P.Ai[p];
-        const int pos = P.pinv[row];
-        slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
-        const int32_t al = P.Alen[p];
-        const int la = slip_abs(al);
-        const dig_t *src = (const dig_t *)(P.Alimbs + P.Aoff[p]);
-        dig_t *X = P.xd + (int64_t) row * P.xcap;
-        SlipRow r; r.len = al; r.h = -1; r.pad = 0; r.bits = 0;
-        if (la > P.xcap) sv[SV_ERR] = 1;
-        else {
-            const int lw = (la + 1) & ~1;
-            for (int c = 0; c < lw; c++) X[c] = c < la ? src[c] : 0u;
-            r.bits = la ? 32 * la - slip_clz32(src[la - 1]) : 0;
-        }
-        P.xrow[row] = r;
-        c_read += 4 + 8 * (unsigned long long)((la + 1) >> 1);
-    }
-    slip_block_sync();
-    if (sv[SV_ERR]) return SLIPDEV_GROW_X;
-    SLIP_STAMP(0);
-
-    /* ---- phase 2: ascending sweep over the pivotal part of the pattern ---- */
-    {
         int cur = -1, step = 0;
         int pj = -1, pjn = -1;                       /* the source whose queued (wave) updates are pending */
         int dj = -1, dys = 1, dh = -1;               /* finalised one-limb source value not yet written back */
@@ -974,12 +980,14 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             }
             pj = j; pjn = jn;
         }
-    }
-    slip_block_sync();
-    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
-    SLIP_STAMP(1);
+}
 
-    /* ---- phase 3: read the bitmap in order = the sorted pattern (slip_sort_xi.c) ---- */
+/* bitmap -> pattern: P.pat[0..npat) = the set pivot positions in ascending order (what slip_sort_xi.c
+ * produces); *nU_out = how many of them are below k.  Called by all threads; ends before a barrier. */
+SLIP_DEV void slip_pattern(const SlipParams &P, uint32_t *lds, const uint32_t *bm, int k, int *npat_out, int *nU_out)
+{
+    const int tid = slip_tid(), T = slip_nthreads();
+    uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
     const int nwords = P.bm_words;
     const int per = (nwords + T - 1) / T;
     int w0 = tid * per, w1 = w0 + per;
@@ -1003,7 +1011,72 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             while (word) { int b = slip_ctz32(word); word &= word - 1; P.pat[o++] = w * 32 + b; }
         }
     }
-    const int npat = (int) totA, nU = (int) totU_, nL = npat - nU;
+    *npat_out = (int) totA; *nU_out = (int) totU_;
+}
+
+/* ------------------------------------------------------------------ */
+/* one column; returns a SLIPDEV_* status (0 = committed)              */
+/* ------------------------------------------------------------------ */
+/* FAST: bitmap and wave scratch both in LDS (addresses provably LDS, ds_* instructions);
+ * otherwise the generic build picks either place at run time (flat addressing). */
+template <bool FAST>
+SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uint32_t *lds,
+                            unsigned long long *t_read, unsigned long long *t_upd,
+                            unsigned long long *t_src, unsigned long long *t_str)
+{
+    const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
+    const int col = P.q[k];
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    volatile int64_t *sv64 = (volatile int64_t *)(lds + SLIP_LDS_VARS);
+    uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
+    uint32_t *work = lds + SLIP_LDS_WORK;
+    uint32_t *bm = BM_LDS ? lds + SLIP_LDS_BITMAP : P.gbitmap;
+    const int wcap = P.wcap;
+    dig_t *b0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
+                        : P.gscratch + (int64_t) wave * 3 * wcap;
+    dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
+    unsigned long long c_read = 0, c_upd = 0, c_src = 0, c_str = 0;
+    SLIP_STAMP_INIT();
+
+    /* ---- phase 0: clear the pattern bitmap ---- */
+    for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
+    if (tid == 0) { sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv64[SV_LALLOC / 2] = 0; sv64[SV_LEXACT / 2] = 0; }
+    slip_block_sync();
+
+    /* ---- phase 1: scatter A(:,col) into x (slip_REF_triangular_solve.c:105-119) ---- */
+    for (int64_t p = P.Ap[col] + tid; p < P.Ap[col + 1]; p += T) {
+        const int row = P.Ai[p];
+        const int pos = P.pinv[row];
+        slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
+        const int32_t al = P.Alen[p];
+        const int la = slip_abs(al);
+        const dig_t *src = (const dig_t *)(P.Alimbs + P.Aoff[p]);
+        dig_t *X = P.xd + (int64_t) row * P.xcap;
+        SlipRow r; r.len = al; r.h = -1; r.pad = 0; r.bits = 0;
+        if (la > P.xcap) sv[SV_ERR] = 1;
+        else {
+            const int lw = (la + 1) & ~1;
+            for (int c = 0; c < lw; c++) X[c] = c < la ? src[c] : 0u;
+            r.bits = la ? 32 * la - slip_clz32(src[la - 1]) : 0;
+        }
+        P.xrow[row] = r;
+        c_read += 4 + 8 * (unsigned long long)((la + 1) >> 1);
+    }
+    slip_block_sync();
+    if (sv[SV_ERR]) return SLIPDEV_GROW_X;
+    SLIP_STAMP(0);
+
+    /* ---- phase 2: ascending sweep over the pivotal part of the pattern ---- */
+    slip_sweep<FAST>(P, k, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str);
+    slip_block_sync();
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+    SLIP_STAMP(1);
+
+    /* ---- phase 3: read the bitmap in order = the sorted pattern (slip_sort_xi.c) ---- */
+    int npat_, nU_;
+    slip_pattern(P, lds, bm, k, &npat_, &nU_);
+    const int npat = npat_, nU = nU_, nL = npat - nU;
     slip_block_sync();
     SLIP_STAMP(2);
 
@@ -1391,6 +1464,240 @@ SLIP_DEV void slip_factor_columns(const SlipParams &P, SlipState *st, uint32_t *
         st->Lnz = sv64[SV_LNZ / 2]; st->Lnl = sv64[SV_LNL / 2]; st->Unz = sv64[SV_UNZ / 2]; st->Unl = sv64[SV_UNL / 2];
         st->Lnl_exact = sv64[SV_LNLX / 2];
         st->k_next = k; st->status = status; st->status_k = k; st->seq = sv[SV_GEN];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* REF forward / back substitution for one right-hand side             */
+/* ------------------------------------------------------------------ */
+/* previous set bit of the bitmap strictly below `from`, or -1 (wave-cooperative) */
+SLIP_DEV int slip_bitmap_prev(const uint32_t *bm, int from)
+{
+    const int lane = slip_lane();
+    if (from <= 0) return -1;
+    int whi = (from - 1) >> 5;                    /* highest word that can hold a candidate */
+    int first = 1;
+    while (whi >= 0) {
+        const int idx = whi - lane;
+        uint32_t word = idx >= 0 ? bm[idx] : 0u;
+        if (first && lane == 0 && (from & 31)) word &= (1u << (from & 31)) - 1u;
+        const uint64_t nz = slip_ballot(word != 0);
+        if (nz) {
+            const int t = slip_ctz64(nz);          /* lowest lane = highest word */
+            const uint32_t wv = slip_shfl_u32(word, t);
+            return (whi - t) * 32 + 31 - slip_clz32(wv);
+        }
+        whi -= SLIP_WAVE; first = 0;
+    }
+    return -1;
+}
+
+template <bool FAST>
+SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveArgs &A, const int c, uint32_t *lds)
+{
+    const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
+    const int n = P.n;
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
+    uint32_t *work = lds + SLIP_LDS_WORK;
+    uint32_t *bm = BM_LDS ? lds + SLIP_LDS_BITMAP : P.gbitmap;
+    const int wcap = P.wcap;
+    dig_t *b0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
+                        : P.gscratch + (int64_t) wave * 3 * wcap;
+    dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
+    unsigned long long c_read = 0, c_upd = 0, c_src = 0, c_str = 0;
+
+    /* b2[pinv[i]] = b[i]  (SLIP_LU_solve.c:68-75): rows keep their ids, the bitmap is indexed by position */
+    for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
+    if (tid == 0) { sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; }
+    slip_block_sync();
+    for (int i = tid; i < n; i += T) {
+        const int32_t bl = A.blen[(int64_t) c * n + i];
+        if (bl == 0) continue;
+        const int pos = P.pinv[i], lb = slip_abs(bl);
+        slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
+        const dig_t *src = (const dig_t *)(A.blimbs + A.boff[(int64_t) c * n + i]);
+        dig_t *X = P.xd + (int64_t) i * P.xcap;
+        SlipRow r; r.len = bl; r.h = -1; r.pad = 0; r.bits = 0;
+        if (lb > P.xcap) sv[SV_ERR] = 1;
+        else {
+            const int lw = (lb + 1) & ~1;
+            for (int d = 0; d < lw; d++) X[d] = d < lb ? src[d] : 0u;
+            r.bits = 32 * lb - slip_clz32(src[lb - 1]);
+        }
+        P.xrow[i] = r;
+    }
+    slip_block_sync();
+    if (sv[SV_ERR]) return SLIPDEV_GROW_X;
+
+    /* forward substitution = the sweep over ALL pivot positions (slip_forward_sub.c:61-158) */
+    slip_sweep<FAST>(P, n, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str);
+    slip_block_sync();
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+
+    /* x <- x * det (slip_array_mul.c:19), det = rho[n-1] */
+    int npat, nUdummy;
+    slip_pattern(P, lds, bm, n, &npat, &nUdummy);
+    slip_block_sync();
+    {
+        volatile int32_t *wcnt = &sv[SV_CNT0];
+        if (tid == 0) *wcnt = 0;
+        slip_block_sync();
+        for (int t0 = 0; t0 < npat; t0 += SLIP_WORK_CAP) {
+            const int te = t0 + SLIP_WORK_CAP < npat ? t0 + SLIP_WORK_CAP : npat;
+            for (int t = t0 + tid; t < te; t += T) {
+                const int r = P.row_perm[P.pat[t]];
+                const SlipRow xr = P.xrow[r];
+                if (xr.len == 0) continue;
+                slip_u128 y = 0; int ys = 1; int done = 0;
+                if (slip_abs(xr.len) <= 2) {
+                    const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                    if (slip_history_small(P, xr, xv, n - 1, -1, &y, &ys)) { slip_store_small(P, r, y, ys, xr.h); done = 1; }
+                }
+                if (!done) { const int at = slip_atomic_add_i32((int32_t *) wcnt, 1); work[at] = (uint32_t) r; }
+            }
+            slip_block_sync();
+            slip_drain(P, lds, 4, 0, 0, n, 0, *wcnt, work, b0, b1, b2);
+            if (tid == 0) *wcnt = 0;
+            slip_block_sync();
+        }
+    }
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+
+    /* back substitution (slip_back_sub.c:36-52): positions descending; x_j /= U_jj (= rho_j, the last entry
+     * of U(:,j)), then x_i -= U_ij x_j for the rows above */
+    {
+        volatile int32_t *wcnt = &sv[SV_CNT0];
+        int cur = n;
+        for (;;) {
+            slip_block_sync();
+            const int jp = slip_bitmap_prev(bm, cur);
+            if (jp < 0) break;
+            cur = jp;
+            const int j = P.row_perm[jp];
+            SlipRow xj = P.xrow[j];
+            if (xj.len == 0) continue;
+            const SlipPiv Dj = P.piv[jp];
+            if (slip_abs(xj.len) <= 2 && slip_abs(Dj.len) <= 2) {
+                const slip_u128 y = slip_divexact128((slip_u128) slip_limb0(P.xd + (int64_t) j * P.xcap), Dj.lo, Dj.ctz, Dj.inv64);
+                slip_block_sync();                                 /* every thread has read the old value */
+                if (tid == 0) slip_store_small(P, j, y, slip_sgn(xj.len) * slip_sgn(Dj.len), xj.h);
+            } else {
+                slip_block_sync();
+                if (wave == 0) { const int e = slip_divexact_wave(P, j, jp, b0, b1, b2, 0, 1); if (e && lane == 0) sv[SV_ERR] = e; }
+            }
+            slip_block_sync();
+            if (sv[SV_ERR]) break;
+            xj = P.xrow[j];
+            const uint64_t xjv = slip_limb0(P.xd + (int64_t) j * P.xcap);
+            const int64_t m0 = P.Up[jp], m1 = P.Up[jp + 1] - 1;   /* the pivot is the last entry */
+            for (int64_t mb = m0; mb < m1; mb += SLIP_WORK_CAP) {
+                const int64_t me = mb + SLIP_WORK_CAP < m1 ? mb + SLIP_WORK_CAP : m1;
+                for (int64_t m = mb + tid; m < me; m += T) {
+                    const int i = P.Ui[m];
+                    const SlipEnt ue = P.Ue[m];
+                    const int pos = P.pinv[i];
+                    const uint32_t bit = 1u << (pos & 31);
+                    const uint32_t old = slip_atomic_or_u32(&bm[pos >> 5], bit);
+                    SlipRow xi;
+                    if (!(old & bit)) { xi.len = 0; xi.h = -1; xi.bits = 0; xi.pad = 0; P.xrow[i] = xi; }
+                    else xi = P.xrow[i];
+                    if (ue.len == 0) continue;
+                    int done = 0;
+                    if (slip_abs(ue.len) <= 2 && slip_abs(xj.len) <= 2 && slip_abs(xi.len) <= 2) {
+                        const int bt = (xi.bits > ue.bits + xj.bits ? xi.bits : ue.bits + xj.bits) + 1;
+                        if (bt <= 126) {
+                            const slip_u128 p2 = (slip_u128) slip_limb0((const dig_t *)(P.Ulimbs + ue.off)) * xjv;
+                            const int s2 = slip_sgn(ue.len) * slip_sgn(xj.len), sx = slip_sgn(xi.len);
+                            slip_u128 mag; int sT;
+                            if (xi.len == 0) { mag = p2; sT = -s2; }
+                            else {
+                                const slip_u128 xv = (slip_u128) slip_limb0(P.xd + (int64_t) i * P.xcap);
+                                if (sx == s2) { if (xv >= p2) { mag = xv - p2; sT = sx; } else { mag = p2 - xv; sT = -sx; } }
+                                else { mag = xv + p2; sT = sx; }
+                            }
+                            slip_store_small(P, i, mag, sT, xi.h);
+                            done = 1;
+                        }
+                    }
+                    if (!done) {
+                        const int at = slip_atomic_add_i32((int32_t *) wcnt, 1);
+                        work[2 * at] = (uint32_t)(m - m0); work[2 * at + 1] = (uint32_t) i;
+                    }
+                }
+                slip_block_sync();
+                slip_drain(P, lds, 5, j, jp, n, m0, *wcnt, work, b0, b1, b2);
+                if (tid == 0) *wcnt = 0;
+                slip_block_sync();
+                if (sv[SV_ERR]) break;
+            }
+            if (sv[SV_ERR]) break;
+        }
+    }
+    slip_block_sync();
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+
+    /* output: numerators in pivot-position order (the order SLIP_LU_solve returns before SLIP_permute_x) */
+    {
+        const int64_t obase = st->out_used;
+        uint64_t run = 0;
+        for (int p0 = 0; p0 < n; p0 += T) {
+            const int pos = p0 + tid;
+            int32_t xl = 0; int r = -1;
+            if (pos < n && ((bm[pos >> 5] >> (pos & 31)) & 1u)) { r = P.row_perm[pos]; xl = P.xrow[r].len; }
+            uint64_t e0, e1, t0_, t1_;
+            slip_block_scan2((uint64_t) slip_limbs(xl), 0, scan_tmp, &e0, &e1, &t0_, &t1_);
+            if (pos < n) {
+                const int64_t off = obase + (int64_t)(run + e0);
+                A.olen[(int64_t) c * n + pos] = xl;
+                A.ooff[(int64_t) c * n + pos] = off;
+                if (xl != 0 && off + slip_limbs(xl) <= A.ocap) {
+                    const dig_t *src = P.xd + (int64_t) r * P.xcap;
+                    dig_t *dst = (dig_t *)(A.olimbs + off);
+                    const int lw = (slip_abs(xl) + 1) & ~1;
+                    for (int d = 0; d < lw; d++) dst[d] = src[d];
+                }
+            }
+            run += t0_;
+        }
+        if (obase + (int64_t) run > A.ocap) return SLIPDEV_GROW_U;       /* output slab too small: the host grows it */
+        slip_block_sync();
+        if (tid == 0) st->out_used = obase + (int64_t) run;
+    }
+    slip_block_sync();
+    return SLIPDEV_OK;
+}
+
+/* kernel body of the solves: block 0 walks the right-hand sides, the others are helpers */
+template <bool FAST>
+SLIP_DEV void slip_solve_all(const SlipParams &P, SlipState *st, const SlipSolveArgs &A, uint32_t *lds)
+{
+    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
+    if (slip_block() != 0) {
+        const int wcap = P.wcap, wave = slip_wave();
+        dig_t *hb0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
+                             : P.gscratch + ((int64_t) slip_block() * slip_nwaves() + wave) * 3 * wcap;
+        slip_helper_loop(P, st, lds, hb0, hb0 + wcap, hb0 + 2 * wcap);
+        return;
+    }
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    if (slip_tid() == 0) sv[SV_GEN] = P.seq0;
+    slip_block_sync();
+    int c = st->solve_next, status = SLIPDEV_OK;
+    for (; c < A.nrhs; c++) {
+        status = slip_solve_rhs<FAST>(P, st, A, c, lds);
+        if (status != SLIPDEV_OK) break;
+    }
+    slip_block_sync();
+    if (slip_tid() == 0) {
+        if (P.nhelpers > 0) {
+            P.batch->kind = 0; P.batch->stamp = sv[SV_GEN] + 1;
+            slip_agent_release();
+            sv[SV_GEN] = sv[SV_GEN] + 1;
+            slip_agent_store_i32(&P.batch->seq, sv[SV_GEN]);
+        }
+        st->solve_next = c; st->status = status; st->status_k = c; st->seq = sv[SV_GEN];
     }
 }
 
