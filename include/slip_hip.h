@@ -13,6 +13,8 @@
  *         slip_sort_xi.c and slip_get_pivot.c:30-183 inside the column loop)
  *   slip_hip_options                     <->  SLIP_options.pivot / .tol
  *        SLIP_LU/Include/SLIP_LU.h:212-223; defaults SLIP_LU_internal.h:136-149
+ *   slip_hip_factor_solve                <->  the integer core of SLIP_LU_solve
+ *        SLIP_LU/Source/SLIP_LU_solve.c:41-86 (slip_forward_sub.c, slip_array_mul.c, slip_back_sub.c)
  *   status codes                         <->  SLIP_info, SLIP_LU.h:160-168
  *
  * The GMP-typed drop-in  SLIP_LU_factorize(L,U,A,S,rhos,pinv,option)  built on
@@ -103,6 +105,20 @@ int slip_hip_factor_download(const slip_hip_factor *f,
                              int64_t *Up, int32_t *Ui, int32_t *Ulen, uint64_t *Ulimbs,
                              int32_t *rholen, uint64_t *rholimbs, int64_t *rho_limbs_inout,
                              int32_t *pinv);
+
+/* REF forward/back substitution on the factors still resident in HBM -- the arithmetic of
+ * SLIP_LU_solve (SLIP_LU/Source/SLIP_LU_solve.c:41-86: b2 = P b, slip_forward_sub.c:61-158,
+ * slip_array_mul.c:19 by det = rhos[n-1], slip_back_sub.c:36-52).  Needs the complete
+ * factorisation (K == n).  b is dense, nrhs columns of n entries in ORIGINAL row order:
+ * blen[c*n+i] = signed limb count, limbs back to back in blimbs in that order.  The result is
+ * what SLIP_LU_solve leaves in x before SLIP_permute_x / the division by det*scale
+ * (SLIP_solve_double etc. do those on the host): integer numerators over det, entry c*n+p for
+ * pivot POSITION p (x_final[q[p]] = xnum[p] / det), same signed-limb-slab form.  *xlen_out and
+ * *xlimbs_out are malloc'ed; release with slip_hip_free. */
+int slip_hip_factor_solve(slip_hip_factor *f, int32_t nrhs, const int32_t *blen, const uint64_t *blimbs,
+                          int32_t **xlen_out, uint64_t **xlimbs_out, int64_t *xnl_out, void *stream);
+/* device time of the solve kernels of the last slip_hip_factor_solve, milliseconds */
+double slip_hip_factor_solve_ms(const slip_hip_factor *f);
 
 void slip_hip_factor_destroy(slip_hip_factor *f);
 

@@ -111,6 +111,30 @@ class Factorization:
         out["info"] = i
         return out
 
+    def solve(self, blen, blimbs, nrhs=1, stream=None):
+        """REF forward/back substitution on the resident factors (slip_hip_factor_solve): dense b in
+        original row order as a limb slab -> (xlen, xlimbs) numerators over det by pivot position."""
+        blen = np.ascontiguousarray(blen, dtype=np.int32)
+        blimbs = np.ascontiguousarray(blimbs, dtype=np.uint64)
+        if blen.size != self.n * nrhs:
+            raise ValueError("blen must hold n*nrhs entries")
+        if blimbs.size == 0:
+            blimbs = np.zeros(1, dtype=np.uint64)
+        pl, px, nl = C.c_void_p(), C.c_void_p(), C.c_int64()
+        rc = self.lib.slip_hip_factor_solve(self.h, int(nrhs), blen.ctypes.data, blimbs.ctypes.data,
+                                            C.byref(pl), C.byref(px), C.byref(nl), C.c_void_p(stream or 0))
+        if rc:
+            raise SlipError(rc, "slip_hip_factor_solve")
+        xlen = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_int32)), shape=(self.n * nrhs,)).copy()
+        xlimbs = (np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint64)), shape=(nl.value,)).copy()
+                  if nl.value else np.zeros(0, np.uint64))
+        self.lib.slip_hip_free(pl)
+        self.lib.slip_hip_free(px)
+        return xlen, xlimbs
+
+    def solve_ms(self):
+        return self.lib.slip_hip_factor_solve_ms(self.h)
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.slip_hip_factor_destroy(self.h)

@@ -77,6 +77,14 @@ slip_factor_kernel(SlipParams P, SlipState *st)
     slip_factor_columns<FAST>(P, st, slip_lds);      /* block 0: column loop; blocks >= 1: helpers */
 }
 
+template <bool FAST>
+__global__ void __launch_bounds__(64 * SLIP_MAX_WAVES)
+slip_solve_kernel(SlipParams P, SlipState *st, SlipSolveArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t slip_lds[];
+    slip_solve_all<FAST>(P, st, A, slip_lds);        /* block 0: the right-hand sides; blocks >= 1: helpers */
+}
+
 /* unit-test kernel: block b performs operation b with one wavefront */
 extern "C" __global__ void __launch_bounds__(64)
 slip_wave_op_kernel(int op, int la, int lb, int W, const uint32_t *a, const uint32_t *b,
@@ -136,7 +144,7 @@ struct slip_hip_factor {
     int32_t n; int64_t annz, alimbs;
     int32_t waves, lds_words, bitmap_in_lds, scratch_in_lds;
     int32_t last_status, window_end, launches;
-    double kernel_ms;
+    double kernel_ms, solve_ms;
     hipEvent_t ev0, ev1;
     /* owned device arrays that are only reachable through const pointers in P */
     int64_t *dAp; int32_t *dAi, *dAlen; int64_t *dAoff; uint64_t *dAlimbs; int32_t *dq;
@@ -392,6 +400,27 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     return SLIP_HIP_OK;
 }
 
+/* new stride of the dense vector; x and the inverse cache are scratch, the pivot records of the
+ * K committed columns survive (their cached inverses are recomputed on demand) */
+static int grow_x_keep(slip_hip_factor *f, int64_t xcap, int32_t K)
+{
+    SlipParams *P = &f->P;
+    if (xcap > (1 << 28)) return SLIP_HIP_OUT_OF_MEMORY;
+    SlipPiv *keep = NULL;
+    if (K > 0) {
+        keep = (SlipPiv *) malloc((size_t) K * sizeof(SlipPiv));
+        if (!keep) return SLIP_HIP_OUT_OF_MEMORY;
+        if (hipMemcpy(keep, P->piv, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(keep); return SLIP_HIP_DEVICE_ERROR; }
+    }
+    int e = alloc_x(f, (int32_t) xcap);
+    if (!e && K > 0) {
+        for (int32_t k = 0; k < K; k++) keep[k].invlen = 0;
+        if (hipMemcpy(P->piv, keep, (size_t) K * sizeof(SlipPiv), hipMemcpyHostToDevice) != hipSuccess) e = SLIP_HIP_DEVICE_ERROR;
+    }
+    free(keep);
+    return e;
+}
+
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
     f->P.seq0 = f->hs.seq;
@@ -454,21 +483,7 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
                 (e = dev_grow(&P->Ulimbs, h->Unl, nl))) { rc = e; break; }
             P->Ucap_nz = nz; P->Ucap_nl = nl;
         } else if (h->status == SLIPDEV_GROW_X) {
-            if ((int64_t) P->xcap * 2 > (1 << 28)) { rc = SLIP_HIP_OUT_OF_MEMORY; break; }
-            /* x and the inverse cache are scratch; the pivot records must survive */
-            SlipPiv *keep = NULL;
-            const int32_t K = h->k_next;
-            if (K > 0) {
-                keep = (SlipPiv *) malloc((size_t) K * sizeof(SlipPiv));
-                if (!keep) { rc = SLIP_HIP_OUT_OF_MEMORY; break; }
-                if (hipMemcpy(keep, P->piv, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(keep); rc = SLIP_HIP_DEVICE_ERROR; break; }
-            }
-            e = alloc_x(f, P->xcap * 2);
-            if (!e && K > 0) {
-                for (int32_t k = 0; k < K; k++) keep[k].invlen = 0;
-                if (hipMemcpy(P->piv, keep, (size_t) K * sizeof(SlipPiv), hipMemcpyHostToDevice) != hipSuccess) e = SLIP_HIP_DEVICE_ERROR;
-            }
-            free(keep);
+            e = grow_x_keep(f, P->xcap * 2, h->k_next);
             if (e) { rc = e; break; }
         } else {
             fprintf(stderr, "slip_hip: kernel stopped with internal status %d at column %d\n", h->status, h->status_k);
@@ -490,6 +505,129 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
     f->last_status = rc;
     return rc;
 }
+
+
+/* ---- REF triangular solves on the resident factors (SLIP_LU_solve.c:41-86) ---- */
+static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, hipStream_t stream)
+{
+    f->P.seq0 = f->hs.seq;
+    f->P.bitmap_in_lds = f->bitmap_in_lds; f->P.scratch_in_lds = f->scratch_in_lds;
+    CK(hipEventRecord(f->ev0, stream));
+#ifndef SLIP_EMULATE
+    const size_t lds_bytes = (size_t) f->lds_words * 4;
+    const dim3 grid(1 + f->P.nhelpers), block(64 * f->waves);
+#define SLIP_LAUNCH(FAST) do { \
+        CK(hipFuncSetAttribute((const void *) slip_solve_kernel<FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes)); \
+        hipLaunchKernelGGL((slip_solve_kernel<FAST>), grid, block, lds_bytes, stream, f->P, f->ds, A); } while (0)
+    if (f->bitmap_in_lds && f->scratch_in_lds) SLIP_LAUNCH(true);
+    else SLIP_LAUNCH(false);
+#undef SLIP_LAUNCH
+    CK(hipGetLastError());
+#else
+    const SlipParams P = f->P; SlipState *ds = f->ds;
+    const int fast = f->bitmap_in_lds && f->scratch_in_lds;
+    emu::launch(1, 64 * f->waves, [P, ds, fast, A]() {
+        if (fast) slip_solve_all<true>(P, ds, A, slip_emu_lds);
+        else slip_solve_all<false>(P, ds, A, slip_emu_lds);
+    });
+#endif
+    CK(hipEventRecord(f->ev1, stream));
+    CK(hipMemcpyAsync(&f->hs, f->ds, sizeof(SlipState), hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, f->ev0, f->ev1));
+    f->solve_ms += ms;
+    return 0;
+}
+
+extern "C" int slip_hip_factor_solve(slip_hip_factor *f, int32_t nrhs, const int32_t *blen, const uint64_t *blimbs,
+                                     int32_t **xlen_out, uint64_t **xlimbs_out, int64_t *xnl_out, void *stream_v)
+{
+    if (!f || nrhs <= 0 || !blen || !blimbs || !xlen_out || !xlimbs_out || !xnl_out) return SLIP_HIP_INCORRECT_INPUT;
+    *xlen_out = NULL; *xlimbs_out = NULL; *xnl_out = 0;
+    const int32_t n = f->n;
+    if (f->hs.k_next != n) return SLIP_HIP_INCORRECT_INPUT;          /* needs the complete factorisation */
+    hipStream_t stream = (hipStream_t) stream_v;
+    SlipParams *P = &f->P;
+    const int64_t ne = (int64_t) n * nrhs;
+    /* b: signed limb counts -> signed digit counts + offsets (zero high limbs trimmed) */
+    int32_t *hlen = (int32_t *) malloc((size_t) ne * 4);
+    int64_t *hoff = (int64_t *) malloc((size_t) ne * 8);
+    if (!hlen || !hoff) { free(hlen); free(hoff); return SLIP_HIP_OUT_OF_MEMORY; }
+    int64_t o = 0; int32_t maxdig = 1;
+    for (int64_t t = 0; t < ne; t++) {
+        int64_t l = blen[t] < 0 ? -(int64_t) blen[t] : blen[t];
+        hoff[t] = o;
+        const uint64_t *src = blimbs + o;
+        o += l;
+        while (l > 0 && src[l - 1] == 0) l--;
+        int32_t dig = (int32_t)(2 * l);
+        if (l > 0 && (src[l - 1] >> 32) == 0) dig--;
+        hlen[t] = blen[t] < 0 ? -dig : dig;
+        if (dig > maxdig) maxdig = dig;
+    }
+    const int64_t bl = o;
+    SlipSolveArgs A; memset(&A, 0, sizeof A);
+    int32_t *dblen = NULL, *dolen = NULL; int64_t *dboff = NULL, *dooff = NULL; uint64_t *dbl = NULL, *dol = NULL;
+    int32_t *xl = NULL; uint64_t *xlimbs = NULL;
+    int rc = 0;
+    /* x grows to about |b| * det: make room once (the kernel still reports GROW_X if this is short) */
+    {
+        int64_t want = 2 * ((int64_t) f->hs.c_maxdig + 2) + maxdig + 8;
+        if (want > P->xcap) rc = grow_x_keep(f, want, n);
+    }
+    int64_t ocap = ne * (((int64_t) f->hs.c_maxdig + maxdig) / 2 + 1) + 64;
+#define A_(call) do { if (!rc) rc = (call); } while (0)
+    A_(dev_alloc(&dblen, ne)); A_(dev_alloc(&dboff, ne)); A_(dev_alloc(&dbl, bl > 0 ? bl : 1));
+    A_(dev_alloc(&dolen, ne)); A_(dev_alloc(&dooff, ne)); A_(dev_alloc(&dol, ocap));
+#undef A_
+    if (!rc && (hipMemcpy(dblen, hlen, (size_t) ne * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dboff, hoff, (size_t) ne * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                (bl > 0 && hipMemcpy(dbl, blimbs, (size_t) bl * 8, hipMemcpyHostToDevice) != hipSuccess)))
+        rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc) {
+        SlipState *h = &f->hs;
+        h->solve_next = 0; h->out_used = 0; h->status = 0;
+        if (hipMemcpy(f->ds, h, sizeof(SlipState), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+        f->solve_ms = 0;
+        A.nrhs = nrhs; A.blen = dblen; A.boff = dboff; A.blimbs = dbl; A.olen = dolen; A.ooff = dooff; A.olimbs = dol; A.ocap = ocap;
+        while (!rc && h->solve_next < nrhs) {
+            int e = launch_solve(f, A, stream);
+            if (e) { rc = e; break; }
+            if (h->status == SLIPDEV_OK) continue;
+            if (h->status == SLIPDEV_GROW_X) rc = grow_x_keep(f, (int64_t) P->xcap * 2, n);
+            else if (h->status == SLIPDEV_GROW_U) {                  /* the output slab */
+                uint64_t *nw = NULL;
+                rc = dev_alloc(&nw, ocap * 2);
+                if (!rc && h->out_used > 0 && hipMemcpy(nw, dol, (size_t) h->out_used * 8, hipMemcpyDeviceToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+                if (!rc) { hipFree(dol); dol = nw; ocap *= 2; A.olimbs = dol; A.ocap = ocap; } else if (nw) hipFree(nw);
+            } else {
+                fprintf(stderr, "slip_hip: solve kernel stopped with internal status %d at right-hand side %d\n", h->status, h->status_k);
+                rc = SLIP_HIP_DEVICE_ERROR;
+            }
+        }
+    }
+    if (!rc) {
+        const int64_t nl = f->hs.out_used;
+        xl = (int32_t *) malloc((size_t) ne * 4);
+        xlimbs = (uint64_t *) malloc((size_t)(nl > 0 ? nl : 1) * 8);
+        if (!xl || !xlimbs) rc = SLIP_HIP_OUT_OF_MEMORY;
+        if (!rc && (hipMemcpy(xl, dolen, (size_t) ne * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                    (nl > 0 && hipMemcpy(xlimbs, dol, (size_t) nl * 8, hipMemcpyDeviceToHost) != hipSuccess)))
+            rc = SLIP_HIP_DEVICE_ERROR;
+        if (!rc) {
+            /* digits -> limbs; entries were laid out in (rhs, position) order, so the slab is already dense */
+            for (int64_t t = 0; t < ne; t++) { const int32_t d = xl[t], l = ((d < 0 ? -d : d) + 1) >> 1; xl[t] = d < 0 ? -l : l; }
+            *xlen_out = xl; *xlimbs_out = xlimbs; *xnl_out = nl;
+            xl = NULL; xlimbs = NULL;
+        }
+    }
+    free(xl); free(xlimbs); free(hlen); free(hoff);
+    hipFree(dblen); hipFree(dboff); hipFree(dbl); hipFree(dolen); hipFree(dooff); hipFree(dol);
+    return rc;
+}
+
+extern "C" double slip_hip_factor_solve_ms(const slip_hip_factor *f) { return f ? f->solve_ms : 0.0; }
 
 /* diagnostic: per-phase shader cycles of the last run (zeros unless built with -DSLIP_PROFILE_PHASES) */
 extern "C" int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out12)

@@ -55,3 +55,47 @@ def check_against_golden(entry, fix, res):
 def hip_lib_path():
     from slip_lu_amd import _lib
     return _lib.DEFAULT_SO
+
+
+def solve_inputs(case):
+    """(n, Ap, Ai, Alen, Alimbs, q, fixture) of one entry of tests/golden/solve_index.json"""
+    import numpy as np
+    import slabfile
+    import oracle_lib
+    fix = slabfile.load(os.path.join(GOLDEN, case["name"] + ".slab.gz"))
+    if case["input"].startswith("gen:"):
+        a, d, b, seed = case["input"][4:].split(",")
+        Ap, Ai, Ax = oracle_lib.matgen(int(a), float(d), int(b), int(seed))
+        Alen, Alimbs = np.sign(Ax).astype(np.int32), np.abs(Ax).astype(np.uint64)
+    else:
+        Ap, Ai, Alen, Alimbs = fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"]
+    return case["n"], Ap, Ai, Alen, Alimbs, fix["q"], fix
+
+
+def check_solve(case, lib_path=None, nrhs=1, **kw):
+    """device solve (slip_hip_factor_solve) == orc_solve numerators, and == the reference's rationals"""
+    from fractions import Fraction
+    import numpy as np
+    import oracle_lib
+    import slip_lu_amd as sl
+    n, Ap, Ai, Alen, Alimbs, q, fix = solve_inputs(case)
+    b = oracle_lib.solve_rhs(n)
+    f = sl.Factorization(n, Ap, Ai, Alen, Alimbs, q, lib_path=lib_path, **kw)
+    try:
+        f.run(0)
+        bs = np.concatenate([b if c % 2 == 0 else -3 * b + c for c in range(nrhs)])
+        blen = np.sign(bs).astype(np.int32); blimbs = np.abs(bs[bs != 0]).astype(np.uint64)
+        xlen, xlimbs = f.solve(blen, blimbs, nrhs=nrhs)
+    finally:
+        f.close()
+    got = oracle_lib.bigints(xlen, xlimbs)
+    want, det = oracle_lib.factorize_and_solve(n, Ap, Ai, Alen, Alimbs, q, b)
+    assert got[:n] == want
+    ref_num = oracle_lib.bigints(fix["xnumlen"], fix["xnumlimbs"])
+    ref_den = oracle_lib.bigints(fix["xdenlen"], fix["xdenlimbs"])
+    for i in range(n):
+        assert Fraction(got[i], det) == Fraction(ref_num[i], ref_den[i]), i
+    for c in range(1, nrhs):
+        bc = b if c % 2 == 0 else -3 * b + c
+        wc, _ = oracle_lib.factorize_and_solve(n, Ap, Ai, Alen, Alimbs, q, bc)
+        assert got[c * n:(c + 1) * n] == wc, c

@@ -29,3 +29,13 @@ def test_emulated_kernel_matches_reference(emu_lib, name, waves, fork_min):
                        pivot=entry["pivot"], tol=entry["tol"], kmax=entry["kmax"], limb_cap=entry["cap"],
                        waves=waves, fork_min=fork_min, lib_path=emu_lib)   # fork_min: batch hand-off path, no helpers
     check_against_golden(entry, fix, res)
+
+
+@pytest.mark.parametrize("name,waves,fork_min,nrhs", [("solve_test_mat", 2, 0, 1), ("solve_gen_n40", 2, 0, 2),
+                                                      ("solve_gen_n40", 4, 1, 1)])
+def test_emulated_solve_matches_reference(emu_lib, name, waves, fork_min, nrhs):
+    """forward / back substitution of the kernel source (slip_solve_rhs) against orc_solve and the reference's x"""
+    import json
+    from conftest import GOLDEN, check_solve
+    case = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "solve_index.json")))}[name]
+    check_solve(case, lib_path=emu_lib, nrhs=nrhs, waves=waves, fork_min=fork_min)
