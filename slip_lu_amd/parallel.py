@@ -94,3 +94,97 @@ def allgather_bigints(dist, lens, limbs, device="cpu"):
     outs = [torch.zeros(cap, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(outs, pad)
     return [unpack_bigints(o.cpu().numpy()[:int(s.item())]) for o, s in zip(outs, sizes)]
+
+
+# ---------------------------------------------------------------------------------------------
+# Subtree farm: independent diagonal blocks of one matrix on different GPUs.
+# Host logic only -- index work and python integers; the factorisations themselves are the HIP path.
+# ---------------------------------------------------------------------------------------------
+def diagonal_blocks(n, Ap, Ai):
+    """Connected components of the row/column graph of A: blocks[t] = sorted ids of block t, or None when
+    some component's row-id set differs from its column-id set (the reference's "diagonal" pivot test
+    reads row id == column id, slip_get_pivot.c:96, so only symmetric id sets can be renumbered locally)."""
+    parent = list(range(2 * n))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for j in range(n):
+        for p in range(int(Ap[j]), int(Ap[j + 1])):
+            a, b = find(n + j), find(int(Ai[p]))
+            if a != b:
+                parent[a] = b
+    rows, cols = {}, {}
+    for i in range(n):
+        rows.setdefault(find(i), []).append(i)
+        cols.setdefault(find(n + i), []).append(i)
+    blocks = []
+    for root, cs in cols.items():
+        if rows.get(root) != cs:
+            return None
+        blocks.append(cs)
+    if sum(len(b) for b in blocks) != n:
+        return None
+    return sorted(blocks)
+
+
+def extract_block(ids, Ap, Ai, Ax, q):
+    """The block's own CSC (ids renumbered by rank, entry order kept) and its column order (q restricted)."""
+    loc = {g: t for t, g in enumerate(ids)}
+    bp, bi, bx = [0], [], []
+    for g in ids:
+        for p in range(int(Ap[g]), int(Ap[g + 1])):
+            bi.append(loc[int(Ai[p])]); bx.append(Ax[p])
+        bp.append(len(bi))
+    bq = [loc[int(c)] for c in q if int(c) in loc]
+    return (np.array(bp, np.int64), np.array(bi, np.int32), bx, np.array(bq, np.int32))
+
+
+def subtree_scales(owner, local_rhos):
+    """sigma[k] for every global column k (in elimination order): the product, over the OTHER blocks, of the
+    last local pivot each of them produced among the global columns < k (1 if none).  owner[k] = block of
+    global column k; local_rhos[t] = that block's pivot chain as python ints.
+    Then  rho[k] = rho_T[k_local] * sigma[k],  L(:,k) = L_T(:,k_local) * sigma[k],  and an entry of U in the
+    row whose pivot sits at global position p is  U_T * sigma[p]  (SURVEY 8(e))."""
+    nb = len(local_rhos)
+    last = [1] * nb
+    done = [0] * nb
+    sigma = []
+    for t in owner:
+        s = 1
+        for u in range(nb):
+            if u != t:
+                s *= last[u]
+        sigma.append(s)
+        last[t] = local_rhos[t][done[t]]
+        done[t] += 1
+    return sigma
+
+
+def assemble_blocks(blocks, q, local):
+    """Recombine per-block factorisations into the global one.  local[t] = dict(rho=[ints], piv_row=[local row id
+    of the pivot of local column k], L=[{local row: int}], U=[{local row: int}]) in local elimination order.
+    Returns dict(rho, piv_row, L, U) with global row ids, columns in global elimination order, entries as
+    {row: value} maps (the entry ORDER inside a column follows the global pinv history and is re-derived by
+    the caller from piv_row; values and patterns are what this function reconstructs)."""
+    block_of = {}
+    for t, ids in enumerate(blocks):
+        for g in ids:
+            block_of[g] = t
+    owner = [block_of[int(c)] for c in q]
+    sigma = subtree_scales(owner, [l["rho"] for l in local])
+    done = [0] * len(blocks)
+    pos_of_row = {}
+    out = dict(rho=[], piv_row=[], L=[], U=[])
+    for k, t in enumerate(owner):
+        kl = done[t]; done[t] += 1
+        ids, l = blocks[t], local[t]
+        prow = ids[l["piv_row"][kl]]
+        pos_of_row[prow] = k
+        out["rho"].append(l["rho"][kl] * sigma[k])
+        out["piv_row"].append(prow)
+        out["L"].append({ids[r]: v * sigma[k] for r, v in l["L"][kl].items()})
+        out["U"].append({ids[r]: v * sigma[pos_of_row[ids[r]]] for r, v in l["U"][kl].items()})
+    return out

@@ -154,3 +154,18 @@ def test_gpu_wave_limb_ops(op):
         rc = lib.slip_hip_wave_op_test(op, nops, la, lb, W, a_.ctypes.data, b_.ctypes.data, out.ctypes.data)
         assert rc == 0
         assert np.array_equal(out, np.array(exp, dtype=np.uint32)), (op, la, lb, W)
+
+
+def test_gpu_subtree_farm_law():
+    """independent diagonal blocks factorised one by one on the HIP path and reassembled with
+    slip_lu_amd.parallel (pivot chains -> scales) equal the HIP factorisation of the whole matrix."""
+    import slip_lu_amd as sl
+    import test_subtree_farm as T
+
+    def gpu_factor(n, Ap, Ai, Ax, q):
+        Alen, Alimbs = sl.ints_to_slab(Ax)
+        r = sl.factorize(n, Ap, Ai, Alen, Alimbs, q)
+        assert r["status"] == 0 and r["K"] == n
+        return r
+    T.check_farm(gpu_factor)
+    T.check_farm(gpu_factor, sizes=(40, 25, 60), seed=5)

@@ -1,0 +1,150 @@
+"""SURVEY 8(e) known-answer test of the subtree farm's scaling law: a matrix made of independent diagonal
+blocks (rows and columns interleaved) factorised (i) whole and (ii) block by block + slip_lu_amd.parallel's
+assembly (pivot chains exchanged, columns rescaled) must agree exactly.  The factoriser in this CPU test is
+the oracle; tests/test_gpu_parity.py::test_gpu_subtree_farm_law runs the same check with the HIP path."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+import oracle_lib
+from conftest import ROOT
+from slip_lu_amd import parallel
+
+
+def make_blocked(sizes, seed, bits=10, density=0.6):
+    """block-diagonal integer matrix, rows and columns interleaved by the same permutation"""
+    rng = np.random.default_rng(seed)
+    n = sum(sizes)
+    ids = rng.permutation(n)
+    cols = [[] for _ in range(n)]
+    o = 0
+    for s in sizes:
+        blk = ids[o:o + s]; o += s
+        for a in range(s):
+            for b in range(s):
+                if a == b or rng.random() < density:
+                    v = int(rng.integers(1, 2 ** bits)) * (1 if rng.random() < 0.5 else -1)
+                    cols[int(blk[b])].append((int(blk[a]), v))
+    Ap, Ai, Ax = [0], [], []
+    for j in range(n):
+        rng.shuffle(cols[j])
+        for i, v in cols[j]:
+            Ai.append(i); Ax.append(v)
+        Ap.append(len(Ai))
+    return n, np.array(Ap, np.int64), np.array(Ai, np.int32), np.array(Ax, np.int64)
+
+
+def as_columns(r):
+    """canonical factor dict -> dict(rho, piv_row, L, U) with {row: value} columns (ORIGINAL row ids)"""
+    n = r["n"]
+    Lx = oracle_lib.bigints(r["Llen"], r["Llimbs"]); Ux = oracle_lib.bigints(r["Ulen"], r["Ulimbs"])
+    rho = oracle_lib.bigints(r["rholen"], r["rholimbs"])
+    inv = np.argsort(r["pinv"])                 # position -> row
+    L = [{int(r["Li"][p]): Lx[p] for p in range(r["Lp"][k], r["Lp"][k + 1])} for k in range(n)]
+    U = [{int(r["Ui"][p]): Ux[p] for p in range(r["Up"][k], r["Up"][k + 1])} for k in range(n)]
+    return dict(rho=rho, piv_row=[int(inv[k]) for k in range(n)], L=L, U=U)
+
+
+def check_farm(factor, sizes=(3, 5, 4), seed=7):
+    n, Ap, Ai, Ax = make_blocked(sizes, seed)
+    q = np.random.default_rng(seed + 1).permutation(n).astype(np.int32)
+    whole = as_columns(factor(n, Ap, Ai, Ax, q))
+    blocks = parallel.diagonal_blocks(n, Ap, Ai)
+    assert blocks is not None and sorted(map(len, blocks)) == sorted(sizes)
+    local = []
+    for ids in blocks:
+        bp, bi, bx, bq = parallel.extract_block(ids, Ap, Ai, Ax, q)
+        local.append(as_columns(factor(len(ids), bp, bi, np.array(bx, np.int64), bq)))
+    got = parallel.assemble_blocks(blocks, q, local)
+    assert got["rho"] == whole["rho"]
+    assert got["piv_row"] == whole["piv_row"]
+    assert got["L"] == whole["L"] and got["U"] == whole["U"]
+    # the law is not vacuous: some scale differs from 1
+    owner = [next(t for t, ids in enumerate(blocks) if int(c) in ids) for c in q]
+    assert any(s != 1 for s in parallel.subtree_scales(owner, [l["rho"] for l in local]))
+
+
+def oracle_factor(n, Ap, Ai, Ax, q):
+    r = oracle_lib.factorize(n, Ap, Ai, np.sign(Ax).astype(np.int32), np.abs(Ax).astype(np.uint64), q)
+    assert r["status"] == 0 and r["K"] == n
+    return r
+
+
+def test_subtree_scaling_law_on_oracle():
+    check_farm(oracle_factor)
+    check_farm(oracle_factor, sizes=(6, 2, 7, 1), seed=19)
+
+
+def test_survey_known_answer():
+    """two 3x3 blocks with local pivot chains a and b: diag(B1,B2) has rho = a0,a1,a2, b0*a2, b1*a2, b2*a2"""
+    sig = parallel.subtree_scales([0, 0, 0, 1, 1, 1], [[-4, 24, 382], [-3, -42, -1165]])
+    assert [r * s for r, s in zip([-4, 24, 382, -3, -42, -1165], sig)] == [-4, 24, 382, -1146, -16044, -445030]
+    sig = parallel.subtree_scales([0, 1, 0, 1, 0, 1], [[-4, 24, 382], [-3, -42, -1165]])     # interleaved
+    assert [r * s for r, s in zip([-4, -3, 24, -42, 382, -1165], sig)] == [-4, 12, -72, -1008, -16044, -445030]
+
+
+WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np
+    from slip_lu_amd import parallel
+    import oracle_lib, test_subtree_farm as T
+    dist = parallel.init("gloo")
+    rank, world, _ = parallel.env_rank()
+    n, Ap, Ai, Ax = T.make_blocked((4, 6, 3, 5), 31)
+    q = np.random.default_rng(32).permutation(n).astype(np.int32)
+    blocks = parallel.diagonal_blocks(n, Ap, Ai)
+    bins = parallel.lpt_partition([len(b) ** 3 for b in blocks], world)
+    mine = {{}}
+    for t in bins[rank]:
+        bp, bi, bx, bq = parallel.extract_block(blocks[t], Ap, Ai, Ax, q)
+        mine[t] = T.as_columns(T.oracle_factor(len(blocks[t]), bp, bi, np.array(bx, np.int64), bq))
+    # the exchange: every rank's pivot chains, packed big integers, one all-gather
+    lens, limbs, tags = [], [], []
+    for t in sorted(mine):
+        for v in mine[t]["rho"]:
+            a = abs(v); l = 0
+            while a:
+                limbs.append(a & (2 ** 64 - 1)); a >>= 64; l += 1
+            lens.append(-l if v < 0 else l)
+        tags.append((t, len(mine[t]["rho"])))
+    gathered = parallel.allgather_bigints(dist, lens, limbs)
+    chains = {{}}
+    for r, (gl, gb) in enumerate(gathered):
+        vals = oracle_lib.bigints(gl, gb); o = 0
+        for t in sorted(bins[r]):
+            chains[t] = vals[o:o + len(blocks[t])]; o += len(blocks[t])
+    block_of = {{g: t for t, ids in enumerate(blocks) for g in ids}}
+    owner = [block_of[int(c)] for c in q]
+    sigma = parallel.subtree_scales(owner, [chains[t] for t in range(len(blocks))])
+    # each rank rescales ITS columns; rank 0 checks them against the whole factorisation
+    whole = T.as_columns(T.oracle_factor(n, Ap, Ai, Ax, q))
+    done = [0] * len(blocks); ok = 1
+    for k, t in enumerate(owner):
+        kl = done[t]; done[t] += 1
+        if t in mine:
+            ok &= mine[t]["rho"][kl] * sigma[k] == whole["rho"][k]
+            ok &= {{blocks[t][r]: v * sigma[k] for r, v in mine[t]["L"][kl].items()}} == whole["L"][k]
+    total = parallel.sum_over_ranks(dist, int(ok))
+    if rank == 0:
+        print(json.dumps(dict(ok=total, world=world)))
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+''')
+
+
+def test_farm_exchange_two_ranks_gloo():
+    path = os.path.join("/tmp", f"slip_farm_worker_{os.getpid()}.py")
+    open(path, "w").write(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", path],
+                         capture_output=True, text=True, env=env, timeout=600)
+    os.unlink(path)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res == dict(ok=2, world=2)
