@@ -132,7 +132,9 @@ typedef struct SlipState {
 
 enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_GEN = 5, SV_LISTN = 6, SV_TMP = 7,
        SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14,
-       SV_LALLOC = 16 /* limbs of the L slab handed out to this column's direct rows */, SV_LEXACT = 18, SV_LNLX = 20 };
+       SV_LALLOC = 16 /* limbs of the L slab handed out to this column's direct rows */, SV_LEXACT = 18, SV_LNLX = 20,
+       SV_PLAN_D = 24 /* batch planning: digits wanted of 1/rho[jn-1] */, SV_PLAN_R = 25 /* ... of 1/rho[jn] */,
+       SV_PLAN_N = 26 /* other (pivot, digits) requests listed in the table area */ };
 
 SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
 SLIP_DEV int slip_abs(int32_t v) { return v < 0 ? -v : v; }
@@ -340,6 +342,16 @@ template <int D> SLIP_DEV int slip_store_x_reg(const SlipParams &P, int i, const
     return 0;
 }
 
+/* make the cached inverse of pivot p cover `want` digits, with whichever arithmetic fits the width */
+SLIP_DEV int slip_ensure_inv_any(const SlipParams &P, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    if (want <= 64)  return slip_ensure_inv_reg<1>(P, p, want, b0, 1);
+    if (want <= 128) return slip_ensure_inv_reg<2>(P, p, want, b0, 1);
+    if (want <= 192) return slip_ensure_inv_reg<3>(P, p, want, b0, 1);
+    if (want <= 256) return slip_ensure_inv_reg<4>(P, p, want, b0, 1);
+    return slip_ensure_inv(P, p, want, b0, b1, b2, 1);
+}
+
 template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, int pm, int pd, dig_t *b0, int mode, int publish)
 {
     const SlipRow xr = P.xrow[r];
@@ -489,6 +501,42 @@ SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t
 /* One IPGE update (slip_REF_triangular_solve.c:156-241) of target row i by source row j
  * (pivot position jn) through the L entry m, one wavefront, everything modulo B^W:
  *     x[i] <- ( hist(x[i]) * rho[jn] - L_m * x[j] ) / rho[jn-1]                          */
+struct SlipIpgePlan { int W, W1, W2, hist, hdiv, fk, Wf, Wall, has_d; };
+
+/* bit bounds -> working widths of one IPGE update; scalar code, shared by the wave that performs the update
+ * and by the lane that plans the inverse cache for a batch (the two must agree digit for digit) */
+SLIP_DEV SlipIpgePlan slip_ipge_plan(const SlipParams &P, int i, int j, int jn, int64_t m, int fuse_k)
+{
+    const SlipRow xi = P.xrow[i], xj = P.xrow[j];
+    const SlipEnt le = P.Le[m];
+    const SlipPiv R = P.piv[jn];
+    SlipIpgePlan pl;
+    const int lx = slip_abs(xi.len), hi = xi.h, br = R.bits;
+    pl.has_d = jn >= 1;
+    int bd = 0, zd = 0;
+    if (pl.has_d) { const SlipPiv D = P.piv[jn - 1]; bd = D.bits; zd = D.ctz; }
+    pl.hist = lx != 0 && pl.has_d && hi < jn - 1;
+    pl.hdiv = pl.hist && hi > -1;
+    int bh = 0, zh = 0;
+    if (pl.hdiv) { const SlipPiv H = P.piv[hi]; bh = H.bits; zh = H.ctz; }
+    const int bxp = !lx ? 0 : (!pl.hist ? xi.bits : (pl.hdiv ? xi.bits + bd - bh + 1 : xi.bits + bd));
+    const int b1b = lx ? bxp + br : 0, b2b = le.bits + xj.bits;
+    const int bnum = (b1b > b2b ? b1b : b2b) + 1;
+    const int bq = pl.has_d ? bnum - bd + 1 : bnum;
+    pl.W = (bq + 1 + 31) >> 5;                       /* + sign bit */
+    pl.W1 = pl.W + (pl.has_d ? ((zd + 31) >> 5) : 0);
+    pl.W2 = pl.W1 + (pl.hdiv ? ((zh + 31) >> 5) : 0);
+    /* last source of the column and a non-pivotal row: fold the history update to level fuse_k-1 in */
+    pl.fk = -1; pl.Wf = 0; pl.Wall = pl.W2;
+    if (pl.W2 <= P.wcap && fuse_k >= 1 && jn < fuse_k - 1 && P.pinv[i] >= fuse_k) {
+        const int bf = bq + P.piv[fuse_k - 1].bits - br + 1;
+        int Wf = (bf + 31) >> 5; if (Wf < 1) Wf = 1;
+        const int need = Wf + ((R.ctz + 31) >> 5);
+        if (need <= 256 && pl.W2 <= 256 && Wf <= P.xcap && Wf <= P.invcap) { pl.fk = fuse_k; pl.Wf = Wf; if (need > pl.Wall) pl.Wall = need; }
+    }
+    return pl;
+}
+
 SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m, dig_t *b0, dig_t *b1, dig_t *b2,
                             int mode = 0, int publish = 1, int fuse_k = -1)
 {
@@ -497,38 +545,21 @@ SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m
     const SlipPiv R = P.piv[jn];
     const int lx = slip_abs(xi.len), sx = slip_sgn(xi.len);
     const dig_t *X = P.xd + (int64_t) i * P.xcap;
-    const int lr = slip_abs(R.len), sr = slip_sgn(R.len), br = R.bits;
+    const int lr = slip_abs(R.len), sr = slip_sgn(R.len);
     const int ll = slip_abs(le.len), sl = slip_sgn(le.len);
     const dig_t *Lm = (const dig_t *)(P.Llimbs + le.off);
     const int lj = slip_abs(xj.len), sj = slip_sgn(xj.len);
     const dig_t *Xj = P.xd + (int64_t) j * P.xcap;
     const int hi = xi.h;
-    const int has_d = jn >= 1;
+    const SlipIpgePlan pl = slip_ipge_plan(P, i, j, jn, m, fuse_k);
+    const int has_d = pl.has_d, hist = pl.hist, hdiv = pl.hdiv, W = pl.W, W1 = pl.W1, W2 = pl.W2;
+    const int fk = pl.fk, Wf = pl.Wf, Wall = pl.Wall;
     SlipPiv D = slip_piv_none();
     if (has_d) D = P.piv[jn - 1];
-    const int ld = slip_abs(D.len), sd = has_d ? slip_sgn(D.len) : 1, bd = D.bits, zd = D.ctz;
-    const int hist = lx != 0 && has_d && hi < jn - 1;
-    const int hdiv = hist && hi > -1;
-    int bh = 0, zh = 0, sh = 1;
-    if (hdiv) { const SlipPiv H = P.piv[hi]; bh = H.bits; zh = H.ctz; sh = slip_sgn(H.len); }
-
-    /* bit bounds -> working widths */
-    const int bxp = !lx ? 0 : (!hist ? xi.bits : (hdiv ? xi.bits + bd - bh + 1 : xi.bits + bd));
-    const int b1b = lx ? bxp + br : 0, b2b = le.bits + xj.bits;
-    const int bnum = (b1b > b2b ? b1b : b2b) + 1;
-    const int bq = has_d ? bnum - bd + 1 : bnum;
-    const int W = (bq + 1 + 31) >> 5;                       /* + sign bit */
-    const int W1 = W + (has_d ? ((zd + 31) >> 5) : 0);
-    const int W2 = W1 + (hdiv ? ((zh + 31) >> 5) : 0);
+    const int ld = slip_abs(D.len), sd = has_d ? slip_sgn(D.len) : 1, zd = D.ctz;
+    int zh = 0, sh = 1;
+    if (hdiv) { const SlipPiv H = P.piv[hi]; zh = H.ctz; sh = slip_sgn(H.len); }
     if (W2 > P.wcap) return 1;
-    /* last source of the column and a non-pivotal row: fold the history update to level fuse_k-1 in */
-    int fk = -1, Wf = 0, Wall = W2;
-    if (fuse_k >= 1 && jn < fuse_k - 1 && P.pinv[i] >= fuse_k) {
-        const int bf = bq + P.piv[fuse_k - 1].bits - br + 1;
-        Wf = (bf + 31) >> 5; if (Wf < 1) Wf = 1;
-        const int need = Wf + ((R.ctz + 31) >> 5);
-        if (need <= 256 && W2 <= 256 && Wf <= P.xcap && Wf <= P.invcap) { fk = fuse_k; if (need > Wall) Wall = need; }
-    }
     /* operands that fit 256 digits stay in registers */
     if (Wall <= 64)  return slip_ipge_wave_reg<1>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish, fk, Wf);
     if (Wall <= 128) return slip_ipge_wave_reg<2>(P, i, j, jn, m, b0, W, W1, hist, hdiv, mode, publish, fk, Wf);
@@ -717,9 +748,47 @@ SLIP_DEV int slip_drain_begin(const SlipParams &P, uint32_t *lds, int kind, int 
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     const int fork = P.fork_min > 0 && nq >= P.fork_min;
     if (!fork) return 0;
-    /* 1. the shared inverse cache must cover the batch before other CUs read it */
-    for (int t = wave; t < nq; t += nw) {
-        const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 1, 1);
+    /* 1. the shared inverse cache must cover the batch before other CUs read it.  One LANE per item works out
+     *    which cached inverses the item divides by and to how many digits (the same width rules the performing
+     *    wave applies): 1/rho[jn-1] and 1/rho[jn] are common to a source's updates and reduce to two maxima,
+     *    the history divisors that are not long enough yet go on a list; then one wave per inverse extends it. */
+    uint32_t *todo = lds + SLIP_LDS_TAB;      /* the column table is not live while batches run */
+    if (tid == 0) { sv[SV_PLAN_D] = 0; sv[SV_PLAN_R] = 0; sv[SV_PLAN_N] = 0; }
+    slip_block_sync();
+    for (int t = tid; t < nq; t += T) {
+        if (kind == 1) {
+            const int i = (int) wl[2 * t + 1];
+            const SlipIpgePlan pl = slip_ipge_plan(P, i, j, jn, m0 + (int64_t) wl[2 * t], k);
+            if (pl.W2 > P.wcap) continue;                              /* the item itself reports the short buffer */
+            if (pl.has_d) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_D], pl.W);
+            if (pl.fk >= 0) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_R], pl.Wf);
+            if (pl.hdiv) {
+                const int h = P.xrow[i].h;
+                if (*(volatile int32_t *) &P.piv[h].invlen < pl.W1) {
+                    const int at = slip_atomic_add_i32((int32_t *) &sv[SV_PLAN_N], 1);
+                    todo[2 * at] = (uint32_t) h; todo[2 * at + 1] = (uint32_t) pl.W1;
+                }
+            }
+        } else if (kind == 2) {
+            const int r = (int) wl[t];
+            const SlipRow xr = P.xrow[r];
+            if (xr.h >= 0) {
+                const int W = (xr.bits + P.piv[k - 1].bits - P.piv[xr.h].bits + 1 + 31) >> 5;
+                if (*(volatile int32_t *) &P.piv[xr.h].invlen < W) {
+                    const int at = slip_atomic_add_i32((int32_t *) &sv[SV_PLAN_N], 1);
+                    todo[2 * at] = (uint32_t) xr.h; todo[2 * at + 1] = (uint32_t) W;
+                }
+            }
+        }
+    }
+    slip_block_sync();
+    {
+        const int wd = sv[SV_PLAN_D], wr = sv[SV_PLAN_R], ntodo = sv[SV_PLAN_N];
+        int e = 0;
+        if (wd > 0 && wave == 0) e = slip_ensure_inv_any(P, jn - 1, wd, b0, b1, b2);
+        if (!e && wr > 0 && wave == 1 % nw) e = slip_ensure_inv_any(P, jn, wr, b0, b1, b2);
+        for (int t = (wave + nw - (2 % nw)) % nw; !e && t < ntodo; t += nw)
+            e = slip_ensure_inv_any(P, (int) todo[2 * t], (int) todo[2 * t + 1], b0, b1, b2);
         if (e && lane == 0) sv[SV_ERR] = e;
     }
     slip_block_sync();
@@ -830,7 +899,9 @@ SLIP_DEV void slip_helper_loop(const SlipParams &P, const SlipState *st, uint32_
         if (tid == 0) { P.dbg[4 * slip_block()] = s; P.dbg[4 * slip_block() + 1] = 2; P.dbg[4 * slip_block() + 2] = kind; P.dbg[4 * slip_block() + 3] = nitems; }
         if (kind == 0) { if (tid == 0) P.dbg[4 * slip_block() + 1] = 4; return; }     /* the column loop has ended */
         const int64_t m0 = B->m0;
-        for (int t = (slip_block() - 1) * nw + wave; t < nitems; t += nw * H) {
+        /* item t -> workgroup t mod H first: a short batch spreads one wave per CU (a wave alone on its SIMD
+         * multiplies at full rate) instead of filling the first few workgroups */
+        for (int t = (slip_block() - 1) + wave * H; t < nitems; t += nw * H) {
             const int e = slip_run_item(P, kind, j, jn, k, m0, P.batch_items, t, b0, b1, b2, 0, 0);
             if (e && lane == 0) sv[SV_ERR] = e == 2 ? 8 : 1;      /* 1: a buffer is too small (the host grows it) */
         }
@@ -1291,7 +1362,14 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                 if (scheme == 3) { num = xp; ln = lp_; den = xc; ldn = lc_; }   /* |small| / |diag| >= tol */
                 else             { num = xc; ln = lc_; den = xp; ldn = lp_; }   /* |diag| / |large| >= tol */
                 const int Wm = ldn + 2;
-                if (Wm > wcap) err = 1;
+                /* tol_m has exactly 53 bits, so tol_m*|den| has 52 or 53 bits more than |den|: most columns
+                 * are decided by the bit lengths alone */
+                const int te0 = P.tol_e;
+                const int bnum_ = (scheme == 3 ? P.xrow[pivrow].bits : P.xrow[col].bits) + (te0 < 0 ? -te0 : 0);
+                const int bden_ = (scheme == 3 ? P.xrow[col].bits : P.xrow[pivrow].bits) + (te0 > 0 ? te0 : 0);
+                if (bnum_ < 52 + bden_) take = 0;
+                else if (bnum_ > 53 + bden_) take = 1;
+                else if (Wm > wcap) err = 1;
                 else {
                     if (lane == 0) { b2[0] = (uint32_t) P.tol_m; b2[1] = (uint32_t)(P.tol_m >> 32); }
                     slip_wave_sync();
@@ -1349,6 +1427,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             if (e < nUe) {
                 const int64_t at = Unz + e;
                 if (at < P.Ucap_nz) { P.Ui[at] = r; SlipEnt en; en.off = Unl + (int64_t)(baseU + (eu & 0xFFFFFFFFull)); en.len = xl; en.bits = xb; P.Ue[at] = en; }
+                if (use_tab) work[e] = (uint32_t)(baseU + (eu & 0xFFFFFFFFull));     /* copy destination inside the U slab */
             } else {
                 const int64_t at = Lnz + (e - nUe);
                 const int64_t off = direct ? doff : Lnl + (int64_t)(lalloc + baseL + el);
@@ -1369,7 +1448,14 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     for (int e = wave; e < nE; e += nw) {
         const int isU = e < nUe;
         const dig_t *srcx; dig_t *dst; int32_t xl;
-        if (use_tab && !isU) {
+        if (use_tab && isU) {
+            /* U(:,k): pivotal rows live in x; the pivot (last) may have been multiplied straight into the L slab */
+            const int pt = e < nU ? e : pividx;
+            xl = (int32_t) tab[4 * pt + 1];
+            srcx = (tab[4 * pt + 3] >> 31) ? (const dig_t *)(P.Llimbs + Lnl + (int64_t)(tab[4 * pt + 3] & 0x7FFFFFFFu))
+                                           : P.xd + (int64_t) tab[4 * pt] * P.xcap;
+            dst = (dig_t *)(P.Ulimbs + Unl + (int64_t) work[e]);
+        } else if (use_tab) {
             const int pt = e - 1;
             if (tab[4 * pt + 3] >> 31) continue;                 /* multiplied straight into the slab */
             xl = (int32_t) tab[4 * pt + 1];

@@ -120,8 +120,10 @@ template <int D> SLIP_DEV WR<D> wr_mul(const WR<D> &A, int la, const WR<D> &B)
         if (steps > 64) steps = 64;
         for (int il = 0; il < steps; il++) {
             const uint32_t a = slip_readlane(A.d[ia], il);
+            /* low product: after 64*ia steps the chunks below ia of the shift register hold only zeros
+             * (column c takes B[c - i], i >= 64*ia), so they neither multiply nor shift */
 #pragma unroll
-            for (int r = 0; r < D; r++) {
+            for (int r = ia; r < D; r++) {
                 const uint64_t p = (uint64_t) a * Bs[r];
                 uint64_t sum;
                 hi[r] += (uint32_t) __builtin_add_overflow(p, acc[r], &sum);
@@ -129,9 +131,9 @@ template <int D> SLIP_DEV WR<D> wr_mul(const WR<D> &A, int la, const WR<D> &B)
             }
             /* shift B one lane up across the chunks: lane l of chunk r now holds B[64r + l - (i+1)] */
 #pragma unroll
-            for (int r = D - 1; r >= 0; r--) {
+            for (int r = D - 1; r >= ia; r--) {
                 uint32_t fill = 0;
-                if (r > 0) fill = slip_readlane(Bs[r - 1], 63);
+                if (r > ia) fill = slip_readlane(Bs[r - 1], 63);
                 Bs[r] = slip_dpp_shr1(Bs[r], fill);
             }
         }
