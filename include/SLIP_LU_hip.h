@@ -16,8 +16,10 @@
  * The same function is also exported as SLIP_hip_LU_factorize, for processes
  * that load both libraries and want to call either explicitly (the tests do).
  *
+ * SLIP_LU_solve (SLIP_LU.h:941-949) is served the same way (SLIP_hip_LU_solve below).
+ *
  * When the reference's SLIP_LU.h has been included first, this header only adds
- * the alias; otherwise it declares layout-compatible mirrors of the four types
+ * the aliases; otherwise it declares layout-compatible mirrors of the four types
  * the call touches (SLIP_LU.h:160-168 SLIP_info, :212-223 SLIP_options,
  * :246-256 SLIP_sparse, :308-316 SLIP_LU_analysis).
  */
@@ -58,12 +60,28 @@ typedef struct {
     int32_t lnz, unz;
 } SLIP_LU_analysis;
 
+typedef struct {                 /* SLIP_LU.h:277-284 */
+    int32_t m, n;
+    mpz_t **x;                   /* x[i][k]: row i of right-hand side k */
+    mpq_t scale;
+} SLIP_dense;
+
+SLIP_info SLIP_LU_solve(mpq_t **x, SLIP_dense *b, const mpz_t *rhos, const SLIP_sparse *L,
+                        const SLIP_sparse *U, const int32_t *pinv);
+
 SLIP_info SLIP_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, SLIP_LU_analysis *S,
                             mpz_t *rhos, int32_t *pinv, SLIP_options *option);
 #endif
 
 SLIP_info SLIP_hip_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, SLIP_LU_analysis *S,
                                 mpz_t *rhos, int32_t *pinv, SLIP_options *option);
+
+/* SLIP_LU_solve (SLIP_LU.h:941-949; SLIP_LU_solve.c:41-86) on the GPU: forward substitution, scaling by
+ * det = rhos[n-1] and back substitution run in slip_hip_factor_solve on the uploaded L, U; the rational
+ * x = b2/det is formed on the host exactly as slip_array_div.c does.  Same arguments, ownership and
+ * error codes as the reference; also exported under the reference's own name. */
+SLIP_info SLIP_hip_LU_solve(mpq_t **x, SLIP_dense *b, const mpz_t *rhos, const SLIP_sparse *L,
+                            const SLIP_sparse *U, const int32_t *pinv);
 
 #ifdef __cplusplus
 }

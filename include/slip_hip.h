@@ -117,6 +117,15 @@ int slip_hip_factor_download(const slip_hip_factor *f,
  * *xlimbs_out are malloc'ed; release with slip_hip_free. */
 int slip_hip_factor_solve(slip_hip_factor *f, int32_t nrhs, const int32_t *blen, const uint64_t *blimbs,
                           int32_t **xlen_out, uint64_t **xlimbs_out, int64_t *xnl_out, void *stream);
+/* A handle around factors the CALLER already holds (what SLIP_LU_solve is given, SLIP_LU.h:941-949), for
+ * slip_hip_factor_solve only (run/reset refuse it).  L, U in the form slip_hip_factor_download produces:
+ * column pointers, ORIGINAL row ids in the reference's entry order (the pivot LAST in every U column,
+ * slip_back_sub.c:43), signed limb counts, limbs back to back; pinv[n].  The pivots rho_k are read from L
+ * (the entry of L(:,k) in the row with pinv == k).  Host pointers, copied. */
+int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
+                                 const int64_t *Lp, const int32_t *Li, const int32_t *Llen, const uint64_t *Llimbs,
+                                 const int64_t *Up, const int32_t *Ui, const int32_t *Ulen, const uint64_t *Ulimbs,
+                                 const int32_t *pinv, const slip_hip_options *opt);
 /* device time of the solve kernels of the last slip_hip_factor_solve, milliseconds */
 double slip_hip_factor_solve_ms(const slip_hip_factor *f);
 

@@ -30,7 +30,8 @@ EXPORTS = ("slip_hip_default_options", "slip_hip_device_count", "slip_hip_factor
            "slip_hip_factor_reset", "slip_hip_factor_run", "slip_hip_factor_info",
            "slip_hip_factor_download", "slip_hip_factor_destroy", "slip_hip_matgen",
            "slip_hip_free", "slip_hip_wave_op_test", "slip_hip_version",
-           "slip_hip_factor_phase_cycles", "slip_hip_factor_solve", "slip_hip_factor_solve_ms")
+           "slip_hip_factor_phase_cycles", "slip_hip_factor_solve", "slip_hip_factor_solve_ms",
+           "slip_hip_factor_from_factors")
 
 _libs = {}
 
@@ -68,6 +69,8 @@ def load(path=None):
     lib.slip_hip_version.restype = C.c_char_p
     lib.slip_hip_factor_solve.argtypes = [vp, C.c_int32, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64), vp]
     lib.slip_hip_factor_solve.restype = C.c_int
+    lib.slip_hip_factor_from_factors.argtypes = [C.POINTER(vp), C.c_int32] + [vp] * 9 + [C.POINTER(Options)]
+    lib.slip_hip_factor_from_factors.restype = C.c_int
     lib.slip_hip_factor_solve_ms.argtypes = [vp]
     lib.slip_hip_factor_solve_ms.restype = C.c_double
     _libs[path] = lib

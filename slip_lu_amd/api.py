@@ -68,6 +68,24 @@ class Factorization:
             self.h = None
             raise SlipError(rc, "slip_hip_factor_create")
 
+    @classmethod
+    def from_factors(cls, fac, waves=0, helpers=-1, fork_min=0, lib_path=None):
+        """A solve-only handle around factors in the form `download()` returns (slip_hip_factor_from_factors)."""
+        self = cls.__new__(cls)
+        self.lib = _lib.load(lib_path)
+        self.n = int(fac["n"])
+        arrs = [np.ascontiguousarray(fac[k], dtype=t) for k, t in (
+            ("Lp", np.int64), ("Li", np.int32), ("Llen", np.int32), ("Llimbs", np.uint64),
+            ("Up", np.int64), ("Ui", np.int32), ("Ulen", np.int32), ("Ulimbs", np.uint64), ("pinv", np.int32))]
+        arrs = [a if a.size else np.zeros(1, a.dtype) for a in arrs]
+        opt = _lib.Options(3, 1.0, 0, waves, 0, 0, helpers, fork_min)
+        self.h = C.c_void_p()
+        rc = self.lib.slip_hip_factor_from_factors(C.byref(self.h), self.n, *[a.ctypes.data for a in arrs], C.byref(opt))
+        if rc:
+            self.h = None
+            raise SlipError(rc, "slip_hip_factor_from_factors")
+        return self
+
     def reset(self):
         rc = self.lib.slip_hip_factor_reset(self.h)
         if rc:

@@ -736,6 +736,26 @@ SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, 
     return slip_history_wave(P, r, k - 1, P.xrow[r].h, b0, b1, b2, mode, publish);
 }
 
+/* planning helper, called by every lane of a wave: the lanes with a request (pivot h to W digits) that name the
+ * same pivot reduce to one list entry carrying the largest width */
+SLIP_DEV void slip_plan_push(volatile int32_t *sv, uint32_t *todo, int has, int h, int W)
+{
+    const int lane = slip_lane();
+    uint64_t pending = slip_ballot(has);
+    while (pending) {
+        const int l0 = slip_ctz64(pending);
+        const int hh = (int) slip_shfl_u32((uint32_t) h, l0);
+        const int mine = has && h == hh;
+        uint32_t w = mine ? (uint32_t) W : 0u;
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = slip_shfl_u32(w, lane ^ d); if (o > w) w = o; }
+        if (lane == l0) {
+            const int at = slip_atomic_add_i32((int32_t *) &sv[SV_PLAN_N], 1);
+            todo[2 * at] = (uint32_t) hh; todo[2 * at + 1] = w;
+        }
+        pending &= ~slip_ballot(mine);
+    }
+}
+
 /* Queue processing in two halves so that the caller can overlap its own work with the helpers:
  *   slip_drain_begin: (fork only) prepare the shared inverse cache, publish the batch; returns 1 if forked
  *   slip_drain_end:   this workgroup's share (or the whole queue when not forked), wait for the helpers
@@ -755,32 +775,28 @@ SLIP_DEV int slip_drain_begin(const SlipParams &P, uint32_t *lds, int kind, int 
     uint32_t *todo = lds + SLIP_LDS_TAB;      /* the column table is not live while batches run */
     if (tid == 0) { sv[SV_PLAN_D] = 0; sv[SV_PLAN_R] = 0; sv[SV_PLAN_N] = 0; }
     slip_block_sync();
-    for (int t = tid; t < nq; t += T) {
-        if (kind == 1) {
-            const int i = (int) wl[2 * t + 1];
-            const SlipIpgePlan pl = slip_ipge_plan(P, i, j, jn, m0 + (int64_t) wl[2 * t], k);
-            if (pl.W2 > P.wcap) continue;                              /* the item itself reports the short buffer */
-            if (pl.has_d) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_D], pl.W);
-            if (pl.fk >= 0) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_R], pl.Wf);
-            if (pl.hdiv) {
-                const int h = P.xrow[i].h;
-                if (*(volatile int32_t *) &P.piv[h].invlen < pl.W1) {
-                    const int at = slip_atomic_add_i32((int32_t *) &sv[SV_PLAN_N], 1);
-                    todo[2 * at] = (uint32_t) h; todo[2 * at + 1] = (uint32_t) pl.W1;
+    if (kind == 1 || kind == 2)
+        for (int t0 = 0; t0 < nq; t0 += T) {
+            const int t = t0 + tid;
+            int has = 0, h = 0, Wh = 0;
+            if (t < nq && kind == 1) {
+                const int i = (int) wl[2 * t + 1];
+                const SlipIpgePlan pl = slip_ipge_plan(P, i, j, jn, m0 + (int64_t) wl[2 * t], k);
+                if (pl.W2 <= P.wcap) {                                     /* else the item itself reports the short buffer */
+                    if (pl.has_d) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_D], pl.W);
+                    if (pl.fk >= 0) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_R], pl.Wf);
+                    if (pl.hdiv) { h = P.xrow[i].h; Wh = pl.W1; has = *(volatile int32_t *) &P.piv[h].invlen < Wh; }
+                }
+            } else if (t < nq) {
+                const SlipRow xr = P.xrow[(int) wl[t]];
+                if (xr.h >= 0) {
+                    h = xr.h;
+                    Wh = (xr.bits + P.piv[k - 1].bits - P.piv[h].bits + 1 + 31) >> 5;
+                    has = *(volatile int32_t *) &P.piv[h].invlen < Wh;
                 }
             }
-        } else if (kind == 2) {
-            const int r = (int) wl[t];
-            const SlipRow xr = P.xrow[r];
-            if (xr.h >= 0) {
-                const int W = (xr.bits + P.piv[k - 1].bits - P.piv[xr.h].bits + 1 + 31) >> 5;
-                if (*(volatile int32_t *) &P.piv[xr.h].invlen < W) {
-                    const int at = slip_atomic_add_i32((int32_t *) &sv[SV_PLAN_N], 1);
-                    todo[2 * at] = (uint32_t) xr.h; todo[2 * at + 1] = (uint32_t) W;
-                }
-            }
+            slip_plan_push(sv, todo, has, h, Wh);
         }
-    }
     slip_block_sync();
     {
         const int wd = sv[SV_PLAN_D], wr = sv[SV_PLAN_R], ntodo = sv[SV_PLAN_N];
@@ -1287,7 +1303,40 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     const int scheme = P.pivot_scheme;
     const int kind = (scheme == 2) ? 2 : ((scheme == 4 || scheme == 5) ? 1 : 0);
     int best = -1;
-    {
+    if (kind != 2 && maxdig < (1 << 18)) {
+        /* one pass: (bit length, leading 40 bits) packed into one key; the candidates that share the best key are
+         * compared exactly, ties towards the earlier pattern position (slip_get_smallest_pivot.c:79) */
+        auto key_of = [&](int t) -> uint64_t {
+            const int32_t xl = ent_len(nU + t);
+            if (xl == 0) return ~0ull;
+            const uint64_t v = ((uint64_t) ent_bits(nU + t) << 40) | (slip_top64(ent_digits(nU + t), slip_abs(xl)) >> 24);
+            return kind == 0 ? v : ~v;
+        };
+        uint64_t mykey = ~0ull, k1 = ~0ull;
+        for (int t = tid; t < nL; t += T) { const uint64_t c = key_of(t); if (t == tid) mykey = c; if (c < k1) k1 = c; }
+        const uint64_t mk = slip_block_min_u64(k1, scan_tmp);
+        if (mk == ~0ull) return SLIPDEV_SINGULAR;
+        if (tid == 0) sv[SV_LISTN] = 0;
+        slip_block_sync();
+        for (int t = tid; t < nL; t += T) {
+            const uint64_t c = t == tid ? mykey : key_of(t);
+            if (c != mk) continue;
+            const int at = slip_atomic_add_i32((int32_t *) &sv[SV_LISTN], 1);
+            if (at < 2 * SLIP_WORK_CAP) work[at] = (uint32_t) t;
+        }
+        slip_block_sync();
+        const int nc = sv[SV_LISTN];
+        /* every wave performs the same reduction (wave-uniform, reads only) */
+        const int listed = nc <= 2 * SLIP_WORK_CAP;
+        for (int c = 0; c < (listed ? nc : nL); c++) {
+            const int t = listed ? (int) work[c] : c;
+            if (!listed && key_of(t) != mk) continue;
+            if (best < 0) { best = t; continue; }
+            const int cmp = wb_cmp(ent_digits(nU + best), slip_abs(ent_len(nU + best)), ent_digits(nU + t), slip_abs(ent_len(nU + t)));
+            if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && t < best)) best = t;
+        }
+        slip_block_sync();
+    } else {
         uint64_t k1 = ~0ull;                                     /* (key, t) packed: smaller is better */
         for (int t = tid; t < nL; t += T) {
             if (ent_len(nU + t) == 0) continue;

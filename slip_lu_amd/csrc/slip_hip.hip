@@ -144,6 +144,7 @@ struct slip_hip_factor {
     int32_t n; int64_t annz, alimbs;
     int32_t waves, lds_words, bitmap_in_lds, scratch_in_lds;
     int32_t last_status, window_end, launches;
+    int32_t factors_only;  /* built from given factors (slip_hip_factor_from_factors): solve only, no A */
     double kernel_ms, solve_ms;
     hipEvent_t ev0, ev1;
     /* owned device arrays that are only reachable through const pointers in P */
@@ -231,7 +232,7 @@ static int alloc_x(slip_hip_factor *f, int32_t xcap)
 
 extern "C" int slip_hip_factor_reset(slip_hip_factor *f)
 {
-    if (!f) return SLIP_HIP_INCORRECT_INPUT;
+    if (!f || f->factors_only) return SLIP_HIP_INCORRECT_INPUT;
     SlipParams *P = &f->P;
     const int32_t n = f->n;
     int32_t *id = (int32_t *) malloc((size_t) n * 4);
@@ -457,7 +458,7 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 
 extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *stream_v)
 {
-    if (!f) return SLIP_HIP_INCORRECT_INPUT;
+    if (!f || f->factors_only) return SLIP_HIP_INCORRECT_INPUT;
     hipStream_t stream = (hipStream_t) stream_v;
     SlipParams *P = &f->P;
     SlipState *h = &f->hs;
@@ -506,6 +507,113 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
     return rc;
 }
 
+
+
+/* ---- a handle around GIVEN factors (the caller's L, U, pinv): what SLIP_LU_solve receives ---- */
+static int slab_to_entries(int64_t nz, const int32_t *len, const uint64_t *limbs, SlipEnt *ent, int32_t *maxdig, int64_t *nl_out)
+{
+    int64_t o = 0;
+    for (int64_t t = 0; t < nz; t++) {
+        int64_t l = len[t] < 0 ? -(int64_t) len[t] : len[t];
+        const uint64_t *src = limbs + o;
+        int64_t le = l;
+        while (le > 0 && src[le - 1] == 0) le--;
+        int32_t dig = (int32_t)(2 * le);
+        if (le > 0 && (src[le - 1] >> 32) == 0) dig--;
+        ent[t].off = o; ent[t].len = len[t] < 0 ? -dig : dig;
+        ent[t].bits = dig ? 32 * dig - __builtin_clz(dig & 1 ? (uint32_t) src[le - 1] : (uint32_t)(src[le - 1] >> 32)) : 0;
+        if (dig > *maxdig) *maxdig = dig;
+        o += l;
+    }
+    *nl_out = o;
+    return 0;
+}
+
+extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
+                                            const int64_t *Lp, const int32_t *Li, const int32_t *Llen, const uint64_t *Llimbs,
+                                            const int64_t *Up, const int32_t *Ui, const int32_t *Ulen, const uint64_t *Ulimbs,
+                                            const int32_t *pinv, const slip_hip_options *opt_in)
+{
+    if (!out || n <= 0 || !Lp || !Li || !Llen || !Llimbs || !Up || !Ui || !Ulen || !Ulimbs || !pinv) return SLIP_HIP_INCORRECT_INPUT;
+    *out = NULL;
+    if (slip_hip_device_count() <= 0) {
+        fprintf(stderr, "slip_hip: no HIP device available -- this library has no CPU fallback\n");
+        return SLIP_HIP_DEVICE_ERROR;
+    }
+    slip_hip_options opt;
+    if (opt_in) opt = *opt_in; else slip_hip_default_options(&opt);
+    const int64_t lnz = Lp[n], unz = Up[n];
+    if (Lp[0] != 0 || Up[0] != 0 || lnz < n || unz < n) return SLIP_HIP_INCORRECT_INPUT;
+    int32_t *rowperm = (int32_t *) malloc((size_t) n * 4);
+    SlipEnt *Le = (SlipEnt *) malloc((size_t) lnz * sizeof(SlipEnt)), *Ue = (SlipEnt *) malloc((size_t) unz * sizeof(SlipEnt));
+    SlipPiv *piv = (SlipPiv *) calloc((size_t) n, sizeof(SlipPiv));
+    if (!rowperm || !Le || !Ue || !piv) { free(rowperm); free(Le); free(Ue); free(piv); return SLIP_HIP_OUT_OF_MEMORY; }
+    int bad = 0;
+    for (int32_t i = 0; i < n; i++) rowperm[i] = -1;
+    for (int32_t i = 0; i < n && !bad; i++) { if (pinv[i] < 0 || pinv[i] >= n || rowperm[pinv[i]] >= 0) bad = 1; else rowperm[pinv[i]] = i; }
+    for (int64_t t = 0; t < lnz && !bad; t++) if (Li[t] < 0 || Li[t] >= n) bad = 1;
+    for (int64_t t = 0; t < unz && !bad; t++) if (Ui[t] < 0 || Ui[t] >= n) bad = 1;
+    int32_t maxdig = 1; int64_t lnl = 0, unl = 0;
+    if (!bad) { slab_to_entries(lnz, Llen, Llimbs, Le, &maxdig, &lnl); slab_to_entries(unz, Ulen, Ulimbs, Ue, &maxdig, &unl); }
+    /* pivot records: rho_k is the entry of L(:,k) in the pivot row (slip_get_pivot.c:178-182) */
+    for (int32_t k = 0; k < n && !bad; k++) {
+        if (Lp[k + 1] < Lp[k] || Up[k + 1] <= Up[k]) { bad = 1; break; }
+        int64_t at = -1;
+        for (int64_t t = Lp[k]; t < Lp[k + 1]; t++) if (Li[t] == rowperm[k]) at = t;
+        if (at < 0 || Le[at].len == 0 || Ui[Up[k + 1] - 1] != rowperm[k]) { bad = 1; break; }
+        const uint64_t *pv = Llimbs + Le[at].off;
+        const int32_t dig = Le[at].len < 0 ? -Le[at].len : Le[at].len;
+        int z = 0; { int64_t w = 0; while (pv[w] == 0) { w++; z += 64; } z += __builtin_ctzll(pv[w]); }
+        SlipPiv pr; memset(&pr, 0, sizeof pr);
+        pr.off = Le[at].off; pr.len = Le[at].len; pr.bits = Le[at].bits; pr.ctz = z; pr.invlen = 0; pr.lo = pv[0];
+        if (dig <= 2) { uint64_t d = pr.lo >> z, x = d; for (int r = 0; r < 5; r++) x *= 2 - d * x; pr.inv64 = x; }
+        piv[k] = pr;
+    }
+    if (bad) { free(rowperm); free(Le); free(Ue); free(piv); return SLIP_HIP_INCORRECT_INPUT; }
+
+    slip_hip_factor *f = (slip_hip_factor *) calloc(1, sizeof(slip_hip_factor));
+    if (!f) { free(rowperm); free(Le); free(Ue); free(piv); return SLIP_HIP_OUT_OF_MEMORY; }
+    SlipParams *P = &f->P;
+    f->n = n; f->factors_only = 1;
+    f->waves = opt.waves > 0 ? opt.waves : 8;
+    P->nhelpers = opt.helpers < 0 ? 63 : (opt.helpers > 255 ? 255 : opt.helpers);
+    P->fork_min = opt.fork_min > 0 ? opt.fork_min : (P->nhelpers > 0 ? 24 : 0);
+#ifdef SLIP_EMULATE
+    P->nhelpers = 0;
+#endif
+    if (f->waves > SLIP_MAX_WAVES) f->waves = SLIP_MAX_WAVES;
+    P->n = n; P->pivot_scheme = opt.pivot; P->limb_cap = 0; P->k_stop = n;
+    P->Lcap_nz = lnz; P->Ucap_nz = unz; P->Lcap_nl = lnl > 0 ? lnl : 1; P->Ucap_nl = unl > 0 ? unl : 1;
+    int rc = 0;
+#define A_(call) do { if (!rc) rc = (call); } while (0)
+    A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n)); A_(dev_alloc(&P->xrow, n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->pat, n));
+    A_(dev_alloc(&P->gbitmap, (int64_t)(n + 31) / 32 + 64));
+    A_(dev_alloc(&P->batch, 1)); A_(dev_alloc(&P->batch_items, SLIP_WORK_WORDS)); A_(dev_alloc(&P->dbg, 4 * 256));
+    A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Li, lnz)); A_(dev_alloc(&P->Le, lnz)); A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
+    A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, unz)); A_(dev_alloc(&P->Ue, unz)); A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
+    A_(dev_alloc(&f->ds, 1));
+    if (!rc && (hipMemset(P->dbg, 0, 4 * 256 * 4) != hipSuccess || hipMemset(P->batch, 0, sizeof(SlipBatch)) != hipSuccess ||
+                hipMemset(P->xrow, 0, (size_t) n * sizeof(SlipRow)) != hipSuccess)) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc) rc = alloc_x(f, 2 * maxdig + 8);                 /* clears piv: upload the records afterwards */
+#undef A_
+#define UP_(dst, src, bytes) do { if (!rc && (bytes) > 0 && hipMemcpy((void *)(dst), (src), (size_t)(bytes), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR; } while (0)
+    UP_(P->pinv, pinv, (size_t) n * 4); UP_(P->row_perm, rowperm, (size_t) n * 4); UP_(P->piv, piv, (size_t) n * sizeof(SlipPiv));
+    UP_(P->Lp, Lp, ((size_t) n + 1) * 8); UP_(P->Li, Li, (size_t) lnz * 4); UP_(P->Le, Le, (size_t) lnz * sizeof(SlipEnt)); UP_(P->Llimbs, Llimbs, (size_t) lnl * 8);
+    UP_(P->Up, Up, ((size_t) n + 1) * 8); UP_(P->Ui, Ui, (size_t) unz * 4); UP_(P->Ue, Ue, (size_t) unz * sizeof(SlipEnt)); UP_(P->Ulimbs, Ulimbs, (size_t) unl * 8);
+    if (!rc && (hipEventCreate(&f->ev0) != hipSuccess || hipEventCreate(&f->ev1) != hipSuccess)) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc) {
+        memset(&f->hs, 0, sizeof f->hs);
+        f->hs.k_next = n; f->hs.Lnz = lnz; f->hs.Unz = unz; f->hs.Lnl = lnl; f->hs.Unl = unl; f->hs.Lnl_exact = lnl;
+        f->hs.c_maxdig = (unsigned long long) maxdig;
+        UP_(f->ds, &f->hs, sizeof(SlipState));
+    }
+#undef UP_
+    free(rowperm); free(Le); free(Ue); free(piv);
+    if (rc) { slip_hip_factor_destroy(f); return rc; }
+    *out = f;
+    return SLIP_HIP_OK;
+}
 
 /* ---- REF triangular solves on the resident factors (SLIP_LU_solve.c:41-86) ---- */
 static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, hipStream_t stream)

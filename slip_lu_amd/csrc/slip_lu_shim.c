@@ -142,6 +142,110 @@ done:
     return ret;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * SLIP_LU_solve (SLIP_LU/Include/SLIP_LU.h:941-949; SLIP_LU/Source/SLIP_LU_solve.c:41-86) on the GPU:
+ * the caller's L, U (permuted row positions, mpz_t values), pinv and the dense right-hand sides go to
+ * the device as limb slabs, slip_hip_factor_solve runs the forward substitution, the scaling by
+ * det = rhos[n-1] and the back substitution, and x[p][k] = numerator / det is formed with GMP exactly
+ * as slip_array_div.c:36-49 does (mpq_set_num, mpq_div: canonical fractions).  x must arrive from
+ * SLIP_create_mpq_mat (initialised), as in SLIP_solve_mpq.c; b is not modified.
+ * ------------------------------------------------------------------------------------------------ */
+static int sparse_to_slab(const SLIP_sparse *M, int32_t n, const int32_t *rowperm,
+                          int64_t **p_out, int32_t **i_out, int32_t **len_out, uint64_t **limbs_out)
+{
+    const int64_t nz = M->p[n];
+    int64_t nl = 0;
+    *p_out = NULL; *i_out = NULL; *len_out = NULL; *limbs_out = NULL;
+    if (nz < n) return 2;                                /* a factor holds at least its diagonal */
+    for (int64_t t = 0; t < nz; t++) nl += (int64_t) mpz_size(M->x[t]);
+    int64_t *p = (int64_t *) malloc(((size_t) n + 1) * 8);
+    int32_t *ids = (int32_t *) malloc((size_t) nz * 4), *len = (int32_t *) malloc((size_t) nz * 4);
+    uint64_t *limbs = (uint64_t *) malloc((size_t)(nl ? nl : 1) * 8);
+    *p_out = p; *i_out = ids; *len_out = len; *limbs_out = limbs;
+    if (!p || !ids || !len || !limbs) return 1;
+    for (int32_t k = 0; k <= n; k++) p[k] = M->p[k];
+    int64_t o = 0;
+    for (int64_t t = 0; t < nz; t++) {
+        if (M->i[t] < 0 || M->i[t] >= n) return 2;
+        ids[t] = rowperm[M->i[t]];                       /* permuted position -> original row id */
+        size_t l = mpz_size(M->x[t]);
+        if (l) memcpy(limbs + o, mpz_limbs_read(M->x[t]), l * 8);
+        len[t] = mpz_sgn(M->x[t]) < 0 ? -(int32_t) l : (int32_t) l;
+        o += (int64_t) l;
+    }
+    return 0;
+}
+
+SLIP_info SLIP_hip_LU_solve(mpq_t **x, SLIP_dense *b, const mpz_t *rhos, const SLIP_sparse *L,
+                            const SLIP_sparse *U, const int32_t *pinv)
+{
+    if (!x || !b || !rhos || !pinv || !L || !U || !b->x
+        || !L->p || !L->i || !L->x || !U->p || !U->i || !U->x)
+        return SLIP_INCORRECT_INPUT;                      /* SLIP_LU_solve.c:51-55 */
+    const int32_t n = L->n, nrhs = b->n;
+    if (n <= 0 || nrhs <= 0) return SLIP_INCORRECT_INPUT;
+    SLIP_info ret = SLIP_OUT_OF_MEMORY;
+    int32_t *rowperm = (int32_t *) malloc((size_t) n * 4), *blen = NULL, *Li = NULL, *Ui = NULL, *Llen = NULL, *Ulen = NULL;
+    int64_t *Lp = NULL, *Up = NULL;
+    uint64_t *blimbs = NULL, *Llimbs = NULL, *Ulimbs = NULL;
+    int32_t *xlen = NULL; uint64_t *xlimbs = NULL; int64_t xnl = 0;
+    slip_hip_factor *f = NULL;
+    mpq_t det2; mpz_t num;
+    int have_gmp = 0, rc;
+    if (!rowperm) goto done;
+    for (int32_t i = 0; i < n; i++) { if (pinv[i] < 0 || pinv[i] >= n) { ret = SLIP_INCORRECT_INPUT; goto done; } rowperm[pinv[i]] = i; }
+    rc = sparse_to_slab(L, n, rowperm, &Lp, &Li, &Llen, &Llimbs);
+    if (!rc) rc = sparse_to_slab(U, n, rowperm, &Up, &Ui, &Ulen, &Ulimbs);
+    if (rc) { if (rc == 2) ret = SLIP_INCORRECT_INPUT; goto done; }
+    /* b: dense, right-hand side k, row i at k*n+i (b->x[i][k], SLIP_LU_solve.c:68-75) */
+    {
+        int64_t nl = 0;
+        for (int32_t i = 0; i < n; i++) for (int32_t k = 0; k < nrhs; k++) nl += (int64_t) mpz_size(b->x[i][k]);
+        blen = (int32_t *) malloc((size_t) n * nrhs * 4);
+        blimbs = (uint64_t *) malloc((size_t)(nl ? nl : 1) * 8);
+        if (!blen || !blimbs) goto done;
+        int64_t o = 0;
+        for (int32_t k = 0; k < nrhs; k++)
+            for (int32_t i = 0; i < n; i++) {
+                size_t l = mpz_size(b->x[i][k]);
+                if (l) memcpy(blimbs + o, mpz_limbs_read(b->x[i][k]), l * 8);
+                blen[(int64_t) k * n + i] = mpz_sgn(b->x[i][k]) < 0 ? -(int32_t) l : (int32_t) l;
+                o += (int64_t) l;
+            }
+    }
+    rc = slip_hip_factor_from_factors(&f, n, Lp, Li, Llen, Llimbs, Up, Ui, Ulen, Ulimbs, pinv, NULL);
+    if (rc == SLIP_HIP_OK) rc = slip_hip_factor_solve(f, nrhs, blen, blimbs, &xlen, &xlimbs, &xnl, NULL);
+    if (rc != SLIP_HIP_OK) { ret = rc == SLIP_HIP_INCORRECT_INPUT ? SLIP_INCORRECT_INPUT : SLIP_OUT_OF_MEMORY; goto done; }
+    /* x = b2 / det (slip_array_div.c:36-49) */
+    mpq_init(det2); mpz_init(num); have_gmp = 1;
+    mpq_set_num(det2, rhos[n - 1]);
+    {
+        int64_t o = 0;
+        for (int32_t k = 0; k < nrhs; k++)
+            for (int32_t p = 0; p < n; p++) {
+                const int32_t sl = xlen[(int64_t) k * n + p];
+                set_from_limbs(num, sl, xlimbs + o);
+                o += sl < 0 ? -sl : sl;
+                mpq_set_num(x[p][k], num);
+                mpz_set_ui(mpq_denref(x[p][k]), 1);
+                mpq_div(x[p][k], x[p][k], det2);
+            }
+    }
+    ret = SLIP_OK;
+done:
+    if (have_gmp) { mpq_clear(det2); mpz_clear(num); }
+    if (f) slip_hip_factor_destroy(f);
+    slip_hip_free(xlen); slip_hip_free(xlimbs);
+    free(rowperm); free(blen); free(blimbs); free(Lp); free(Li); free(Llen); free(Llimbs); free(Up); free(Ui); free(Ulen); free(Ulimbs);
+    return ret;
+}
+
+SLIP_info SLIP_LU_solve(mpq_t **x, SLIP_dense *b, const mpz_t *rhos, const SLIP_sparse *L,
+                        const SLIP_sparse *U, const int32_t *pinv)
+{
+    return SLIP_hip_LU_solve(x, b, rhos, L, U, pinv);
+}
+
 /* the reference's symbol: interposes when this library is linked ahead of libsliplu */
 SLIP_info SLIP_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, SLIP_LU_analysis *S,
                             mpz_t *rhos, int32_t *pinv, SLIP_options *option)

@@ -1,7 +1,7 @@
 /* dropin_driver.c -- the drop-in acceptance test, in the shape of the reference's own demo
  * (SLIP_LU/Demo/SLIPLU.c:152-367): a program written against the REFERENCE's public header and
  * library whose SLIP_LU_factorize call is served by whichever library comes first on the link
- * line -- libslip_lu_hip.so (HIP path) or the reference itself.  TEST ONLY; compiled here, where
+ * line -- libslip_lu_hip.so (HIP path; it serves SLIP_LU_solve as well) or the reference itself.  TEST ONLY; compiled here, where
  * the reference's headers exist (tests/dropin/Makefile), the binaries travel to the GPU box.
  *
  *   dropin_driver <triplet file> [pivot]
@@ -60,7 +60,9 @@ int main(int argc, char **argv)
 
     OK(SLIP_LU_analyze(S, A, option));
     OK(SLIP_LU_factorize(L, U, A, S, rhos, pinv, option));        /* <-- the replaced call */
-    OK(SLIP_LU_solve(x, b, rhos, L, U, pinv));
+    OK(SLIP_LU_solve(x, b, rhos, L, U, pinv));                    /* <-- replaced too (HIP forward/back substitution) */
+    uint64_t hx = 1469598103934665603ULL;                         /* the exact rational solution, before permute */
+    for (int32_t i = 0; i < n; i++) { hx = fnv_mpz(hx, mpq_numref(x[i][0])); hx = fnv_mpz(hx, mpq_denref(x[i][0])); }
     OK(SLIP_permute_x(x, n, 1, S));
     SLIP_info check = SLIP_check_solution(A, x, b);
 
@@ -72,8 +74,8 @@ int main(int argc, char **argv)
     h = fnv(h, U->p, ((size_t) n + 1) * 4); h = fnv(h, U->i, (size_t) U->nz * 4);
     for (int32_t t = 0; t < L->nz; t++) { blu += mpz_sizeinbase(L->x[t], 2); h = fnv_mpz(h, L->x[t]); }
     for (int32_t t = 0; t < U->nz; t++) { blu += mpz_sizeinbase(U->x[t], 2); h = fnv_mpz(h, U->x[t]); }
-    printf("check=%d nzmaxL=%d nzL=%d nzmaxU=%d nzU=%d report %zu %zu %d hash %016llx\n", (int) check,
-           L->nzmax, L->nz, U->nzmax, U->nz, brho, blu - brho, L->nz + U->nz - n, (unsigned long long) h);
+    printf("check=%d nzmaxL=%d nzL=%d nzmaxU=%d nzU=%d report %zu %zu %d hash %016llx xhash %016llx\n", (int) check,
+           L->nzmax, L->nz, U->nzmax, U->nz, brho, blu - brho, L->nz + U->nz - n, (unsigned long long) h, (unsigned long long) hx);
 
     /* the caller owns everything: free through the reference's own destructors */
     SLIP_delete_sparse(&A); SLIP_delete_sparse(&L); SLIP_delete_sparse(&U);

@@ -75,3 +75,32 @@ def test_gpu_solve_residual_and_linearity(n, density, bits, seed, with_oracle):
         return
     want, _ = oracle_lib.factorize_and_solve(n, Ap, Ai, Alen, Alimbs, q, np.array(b1, dtype=np.int64))
     assert x1 == want
+
+
+def test_gpu_solve_on_uploaded_factors():
+    """slip_hip_factor_from_factors: the factors go to the host and back (what the SLIP_LU_solve drop-in does) and the
+    solve on the uploaded copy equals the solve on the resident factorisation; such a handle refuses run/reset."""
+    import slip_lu_amd as sl
+    from conftest import solve_inputs
+    n, Ap, Ai, Alen, Alimbs, q, _ = solve_inputs(CASES["solve_10teams"])
+    b = oracle_lib.solve_rhs(n)
+    blen, blimbs = np.sign(b).astype(np.int32), np.abs(b[b != 0]).astype(np.uint64)
+    f = sl.Factorization(n, Ap, Ai, Alen, Alimbs, q)
+    try:
+        f.run(0)
+        fac = f.download()
+        x1 = f.solve(blen, blimbs)
+    finally:
+        f.close()
+    g = sl.Factorization.from_factors(fac)
+    try:
+        x2 = g.solve(blen, blimbs)
+        assert g.run(0, check=False) == -3                     # SLIP_INCORRECT_INPUT: no A behind this handle
+        with pytest.raises(sl.api.SlipError):
+            g.reset()
+    finally:
+        g.close()
+    assert np.array_equal(x1[0], x2[0]) and np.array_equal(x1[1], x2[1])
+    bad = dict(fac); bad["pinv"] = np.zeros(n, np.int32)
+    with pytest.raises(sl.api.SlipError):
+        sl.Factorization.from_factors(bad)
