@@ -1328,11 +1328,14 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         const int nc = sv[SV_LISTN];
         /* every wave performs the same reduction (wave-uniform, reads only) */
         const int listed = nc <= 2 * SLIP_WORK_CAP;
+        const int kbits = (int)((kind == 0 ? mk : ~mk) >> 40);   /* at most 40 bits: equal keys are equal values */
         for (int c = 0; c < (listed ? nc : nL); c++) {
             const int t = listed ? (int) work[c] : c;
             if (!listed && key_of(t) != mk) continue;
             if (best < 0) { best = t; continue; }
-            const int cmp = wb_cmp(ent_digits(nU + best), slip_abs(ent_len(nU + best)), ent_digits(nU + t), slip_abs(ent_len(nU + t)));
+            int cmp = 0;
+            if (kbits > 40)
+                cmp = wb_cmp(ent_digits(nU + best), slip_abs(ent_len(nU + best)), ent_digits(nU + t), slip_abs(ent_len(nU + t)));
             if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && t < best)) best = t;
         }
         slip_block_sync();

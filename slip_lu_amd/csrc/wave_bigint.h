@@ -234,7 +234,10 @@ SLIP_DEV void wb_inv_extend(dig_t *inv, int have, int want, const dig_t *dodd, i
         have = 1;
     }
     while (have < want) {
-        int m2 = 2 * have < want ? 2 * have : want;
+        /* halving chain down from `want`: the last (most expensive) step doubles exactly onto the target
+         * instead of repeating a full-length step for a few extra digits */
+        int m2 = want;
+        while (m2 > 2 * have) m2 = (m2 + 1) >> 1;
         wb_mul_lo(e, dodd, ld < m2 ? ld : m2, inv, have, m2);
         wb_addsub(e, (const dig_t *) 0, 1, e, m2, m2, 1, 2u);      /* e = 2 - d*v */
         wb_mul_lo(t, inv, have, e, m2, m2);

@@ -123,21 +123,16 @@ template <int D> SLIP_DEV WR<D> wr_mul(const WR<D> &A, int la, const WR<D> &B)
             /* low product: after 64*ia steps the chunks below ia of the shift register hold only zeros
              * (column c takes B[c - i], i >= 64*ia), so they neither multiply nor shift */
 #pragma unroll
-            for (int r = ia; r < D; r++) {
-                const uint64_t p = (uint64_t) a * Bs[r];
-                uint64_t sum;
-                hi[r] += (uint32_t) __builtin_add_overflow(p, acc[r], &sum);
-                acc[r] = sum;
-            }
+            for (int r = ia; r < D; r++) slip_mac96(acc[r], hi[r], a, Bs[r]);
             /* shift B one lane up across the chunks: lane l of chunk r now holds B[64r + l - (i+1)] */
 #pragma unroll
             for (int r = D - 1; r >= ia; r--) {
-                uint32_t fill = 0;
-                if (r > ia) fill = slip_readlane(Bs[r - 1], 63);
-                Bs[r] = slip_dpp_shr1(Bs[r], fill);
+                if (r > ia) Bs[r] = slip_dpp_shr1_in(Bs[r], slip_readlane(Bs[r - 1], 63));
+                else Bs[r] = slip_dpp_shr1_zero(Bs[r]);
             }
         }
     }
+    slip_valu_settle();
     uint32_t lo[D], mid[D];
 #pragma unroll
     for (int r = 0; r < D; r++) { lo[r] = (uint32_t) acc[r]; mid[r] = (uint32_t)(acc[r] >> 32); }
@@ -209,7 +204,9 @@ template <int D> SLIP_DEV WR<D> wr_inv_extend(WR<D> V, int have, int want, const
     WR<D> two = wr_zero<D>();
     if (lane == 0) two.d[0] = 2u;
     while (have < want) {
-        const int m2 = 2 * have < want ? 2 * have : want;
+        /* halving chain down from `want` (see wb_inv_extend): 1 -> 2 -> 3 -> 5 -> ... -> want/2 -> want */
+        int m2 = want;
+        while (m2 > 2 * have) m2 = (m2 + 1) >> 1;
         WR<D> e = wr_mul<D>(V, have, Dodd);              /* d*v, V's `have` digits walked */
         e = wr_mask<D>(wr_addsub<D>(two, e, 1), m2);     /* 2 - d*v  mod B^m2 */
         V = wr_mask<D>(wr_mul<D>(V, have, e), m2);

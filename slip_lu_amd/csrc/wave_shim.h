@@ -39,6 +39,16 @@ static inline uint32_t slip_emu_shl1(const uint64_t *o, uint32_t fill) { int l =
 #define slip_dpp_shr1(v, fill) slip_emu_shr1(emu::collective((uint64_t)(v), __LINE__), (fill))
 #define slip_dpp_shl1(v, fill) slip_emu_shl1(emu::collective((uint64_t)(v), __LINE__), (fill))
 #define slip_readlane(v, lane) ((uint32_t) emu::shfl((uint64_t)(v), (lane), __LINE__))
+#define slip_dpp_shr1_in(v, in) slip_dpp_shr1((v), (in))
+#define slip_dpp_shr1_zero(v) slip_dpp_shr1((v), 0u)
+static inline void slip_valu_settle(void) {}
+/* (hi:acc) += a * b, a 96-bit per-lane accumulator */
+static inline void slip_mac96(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t b)
+{
+    const uint64_t p = (uint64_t) a * b, sum = acc + p;
+    hi += (uint32_t)(sum < p);
+    acc = sum;
+}
 static inline uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 static inline int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v > o) *p = v; return o; }
 static inline int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
@@ -98,6 +108,25 @@ SLIP_DEV uint32_t slip_dpp_shl1(uint32_t v, uint32_t fill)
     return (uint32_t) __builtin_amdgcn_update_dpp((int) fill, (int) v, 0x130, 0xF, 0xF, false);
 }
 SLIP_DEV uint32_t slip_readlane(uint32_t v, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) v, lane); }
+/* wave shift by one lane with a wave-uniform value entering lane 0: zero-filling DPP move (no `old` operand to
+ * set up) + v_writelane */
+SLIP_DEV uint32_t slip_dpp_shr1_in(uint32_t v, uint32_t in)
+{
+    uint32_t sh = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x138, 0xF, 0xF, true);
+    asm("v_writelane_b32 %0, %1, 0" : "+v"(sh) : "s"(in));
+    return sh;
+}
+/* results of the inline-asm VALU ops above may be read by a DPP op next: give the pipeline its two wait states */
+SLIP_DEV void slip_valu_settle(void) { asm volatile("s_nop 1"); }
+SLIP_DEV uint32_t slip_dpp_shr1_zero(uint32_t v) { return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x138, 0xF, 0xF, true); }
+/* (hi:acc) += a * b with a wave-uniform (SGPR): v_mad_u64_u32 accumulates in place and hands its carry to one
+ * v_addc -- the compiler's own expansion of the same C is mad + 64-bit add + 64-bit compare + addc */
+SLIP_DEV void slip_mac96(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t b)
+{
+    uint64_t cy;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2"
+        : "+v"(acc), "+v"(hi), "=&s"(cy) : "s"(a), "v"(b));
+}
 SLIP_DEV uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 SLIP_DEV int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { return atomicMax(p, v); }
 SLIP_DEV int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { return atomicAdd(p, v); }
