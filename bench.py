@@ -130,10 +130,10 @@ def main():
     assert info["b_read"] == idx["counters"]["B_read"] and info["b_write"] == idx["counters"]["B_write"]
 
     # HBM traffic per launch from the PMC passes of this round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    # separate runs; profiles/r01/v4_pmc_summary.json): counters cannot be read from inside this process
+    # separate runs; profiles/r01/v5_pmc_summary.json): counters cannot be read from inside this process
     traffic = None
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01", "v4_pmc_summary.json")))["hbm_bytes_per_launch"]
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01", "v5_pmc_summary.json")))["hbm_bytes_per_launch"]
     except Exception:
         pass
 
@@ -146,12 +146,21 @@ def main():
                 e, fx = load_case(name)
                 g = sl.Factorization(e["n"], fx["Ap"], fx["Ai"], fx["Alen"], fx["Alimbs"], fx["q"], limb_cap=e["cap"])
                 g.run(e["kmax"]); g.reset(); g.run(e["kmax"])
-                gi = g.info(); g.close()
+                gi = g.info()
                 nz = gi["lnz"] + gi["unz"] - gi["K"]
                 assert nz == e["lnz"] + e["unz"] - e["K"] and gi["b_read"] == e["counters"]["B_read"]
-                secondary.append(dict(workload=name, columns=gi["K"], lu_nnz=nz, max_limbs=gi["max_limbs"],
-                                      kernel_ms=gi["kernel_ms"], lu_nnz_per_s=nz / (gi["kernel_ms"] * 1e-3),
-                                      reference_cpu_seconds_build_container=e["ref_seconds"]))
+                rec = dict(workload=name, columns=gi["K"], lu_nnz=nz, max_limbs=gi["max_limbs"],
+                           kernel_ms=gi["kernel_ms"], lu_nnz_per_s=nz / (gi["kernel_ms"] * 1e-3),
+                           reference_cpu_seconds_build_container=e["ref_seconds"])
+                if gi["K"] == e["n"]:
+                    # next row of the scope table: SLIP_LU_solve's substitutions on the resident factors, one
+                    # right-hand side (the deterministic b of the solve goldens), second run timed
+                    b = (np.arange(e["n"], dtype=np.int64) * 2654435761 % (1 << 32)) % 2001 - 1000
+                    bl, bx = np.sign(b).astype(np.int32), np.abs(b[b != 0]).astype(np.uint64)
+                    g.solve(bl, bx); g.solve(bl, bx)
+                    rec["solve_kernel_ms"] = g.solve_ms()
+                g.close()
+                secondary.append(rec)
             except Exception as ex:                  # never let a side measurement break the headline
                 secondary.append(dict(workload=name, error=str(ex)))
 

@@ -128,7 +128,9 @@ typedef struct SlipState {
 #define SLIP_WORK_WORDS    (6 * SLIP_WORK_CAP)
 #define SLIP_LDS_TAB       (SLIP_LDS_WORK + SLIP_WORK_WORDS)   /* column table: row, len, bits, slab offset per pattern entry */
 #define SLIP_TAB_CAP       1024
-#define SLIP_LDS_BITMAP    (SLIP_LDS_TAB + 4 * SLIP_TAB_CAP)
+#define SLIP_PAT_CAP       1024     /* a pattern of at most this many entries stays in LDS               */
+#define SLIP_LDS_PAT       (SLIP_LDS_TAB + 4 * SLIP_TAB_CAP)
+#define SLIP_LDS_BITMAP    (SLIP_LDS_PAT + SLIP_PAT_CAP)
 
 enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_GEN = 5, SV_LISTN = 6, SV_TMP = 7,
        SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14,
@@ -651,12 +653,12 @@ SLIP_DEV uint64_t slip_top64(const dig_t *X, int l)
 
 /* rows[t] (one-limb values, never updated: h < 0) times the long pivot M: the pivot's digits stay in
  * registers, every wave takes rows in turn (slip_REF_triangular_solve.c:248-257 for untouched rows) */
-template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, const uint32_t *recs, int nrows,
-                                                int64_t slab_base)
+template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, const uint32_t *recs,
+                                                int first, int stride, int nrows, int64_t slab_base)
 {
-    const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    const int lane = slip_lane();
     const WR<D> Mr = wr_load<D>(Md, slip_abs(M.len));
-    for (int t = wave; t < nrows; t += nw) {
+    for (int t = first; t < nrows; t += stride) {
         /* record written by the classifying lane: row, low/high digit of the one-limb value, signed length,
          * and the slot of the L slab reserved for the product (these rows ARE L(:,k): no second copy) */
         const int r = (int) recs[5 * t];
@@ -678,6 +680,20 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
         }
     }
     return 0;
+}
+
+/* rows [first, first+stride, ...) of a column's one-limb-times-pivot list (5-word records), pivot rho[k-1];
+ * Md: staged copy of the pivot's digits, or null to read them from the L slab */
+SLIP_DEV int slip_mul_rows_any(const SlipParams &P, int k, const dig_t *Md, const uint32_t *recs, int first, int stride, int nrows,
+                               int64_t slab_base)
+{
+    const SlipPiv M = P.piv[k - 1];
+    if (!Md) Md = slip_piv_digits(P, M);
+    const int Dm = (slip_abs(M.len) + 2 + 63) >> 6;
+    if (Dm <= 1) return slip_mul_rows_reg<1>(P, M, Md, recs, first, stride, nrows, slab_base);
+    if (Dm == 2) return slip_mul_rows_reg<2>(P, M, Md, recs, first, stride, nrows, slab_base);
+    if (Dm == 3) return slip_mul_rows_reg<3>(P, M, Md, recs, first, stride, nrows, slab_base);
+    return slip_mul_rows_reg<4>(P, M, Md, recs, first, stride, nrows, slab_base);
 }
 
 /* ------------------------------------------------------------------ */
@@ -725,12 +741,14 @@ SLIP_DEV int slip_submul_wave(const SlipParams &P, int i, int j, int64_t m, dig_
     return slip_store_x(P, i, b1, W, sT, xi.h);
 }
 
-/* kind 1: k is the fuse level (-1: none) of the IPGE updates; kind 2: k is the column of the history rows */
+/* kind 1: k is the fuse level (-1: none) of the IPGE updates; kind 2: k is the column of the history rows;
+ * kind 3: one-limb rows times rho[k-1] straight into the L slab (5-word records, m0 = slab base) */
 SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, int64_t m0, const uint32_t *items, int t,
                            dig_t *b0, dig_t *b1, dig_t *b2, int mode, int publish)
 {
     if (kind == 1) return slip_ipge_wave(P, (int) items[2 * t + 1], j, jn, m0 + (int64_t) items[2 * t], b0, b1, b2, mode, publish, k);
     if (kind == 5) return slip_submul_wave(P, (int) items[2 * t + 1], j, m0 + (int64_t) items[2 * t], b0, b1, b2, mode);
+    if (kind == 3) return mode == 1 ? 0 : slip_mul_rows_any(P, k, (const dig_t *) 0, items, t, 0x40000000, t + 1, m0);   /* m0 = slab base */
     const int r = (int) items[t];
     if (kind == 4) return slip_history_wave(P, r, k - 1, -1, b0, b1, b2, mode, publish);      /* x * rho[k-1] */
     return slip_history_wave(P, r, k - 1, P.xrow[r].h, b0, b1, b2, mode, publish);
@@ -811,7 +829,7 @@ SLIP_DEV int slip_drain_begin(const SlipParams &P, uint32_t *lds, int kind, int 
     if (sv[SV_ERR]) return 0;                 /* _end will see the error and do nothing */
     /* 2. publish: items and descriptor to HBM, agent-scope release, bump the generation */
     SlipBatch *B = P.batch;
-    const int nwords = (kind == 1 || kind == 5) ? 2 * nq : nq;
+    const int nwords = (kind == 1 || kind == 5) ? 2 * nq : (kind == 3 ? 5 * nq : nq);
     for (int t = tid; t < nwords; t += T) P.batch_items[t] = wl[t];
     if (tid == 0) {
         B->kind = kind; B->nitems = nq; B->j = j; B->jn = jn; B->k = k; B->m0 = m0; B->stamp = sv[SV_GEN] + 1;
@@ -1092,10 +1110,16 @@ SLIP_DEV void slip_pattern(const SlipParams &P, uint32_t *lds, const uint32_t *b
     uint64_t exA, exU, totA, totU_;
     slip_block_scan2(cntA, cntU, scan_tmp, &exA, &exU, &totA, &totU_);
     {
+        /* short patterns never leave the CU (the readers pick the same place by npat) */
         int o = (int) exA;
+        int32_t *patl = (int32_t *)(lds + SLIP_LDS_PAT);
+        const bool in_lds = totA <= SLIP_PAT_CAP;
         for (int w = w0; w < w1; w++) {
             uint32_t word = bm[w];
-            while (word) { int b = slip_ctz32(word); word &= word - 1; P.pat[o++] = w * 32 + b; }
+            while (word) {
+                int b = slip_ctz32(word); word &= word - 1;
+                if (in_lds) patl[o++] = w * 32 + b; else P.pat[o++] = w * 32 + b;
+            }
         }
     }
     *npat_out = (int) totA; *nU_out = (int) totU_;
@@ -1164,6 +1188,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     int npat_, nU_;
     slip_pattern(P, lds, bm, k, &npat_, &nU_);
     const int npat = npat_, nU = nU_, nL = npat - nU;
+    const int32_t *patl = (const int32_t *)(lds + SLIP_LDS_PAT);
+    auto pat_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? patl[t] : P.pat[t]; };
     slip_block_sync();
     SLIP_STAMP(2);
 
@@ -1187,7 +1213,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             const int te = t0 + SLIP_WORK_CAP < nL ? t0 + SLIP_WORK_CAP : nL;
             const unsigned long long chunk_base = (unsigned long long) sv64[SV_LALLOC / 2];
             for (int t = t0 + tid; t < te; t += T) {
-                const int r = P.row_perm[P.pat[nU + t]];
+                const int r = P.row_perm[pat_at(nU + t)];
                 const SlipRow xr = P.xrow[r];
                 if (xr.len == 0 || xr.h >= k - 1) continue;
                 int done = 0;
@@ -1238,20 +1264,17 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             /* the history rows that need a division go to the helpers first; the one-limb-times-pivot rows
              * are multiplied here meanwhile */
             const int forked = slip_drain_begin(P, lds, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
-            {
-                const int n2 = *wcnt2;
-                if (n2 > 0) {
-                    const int Dm = (lm + 2 + 63) >> 6;
-                    int e;
-                    const int64_t sb = sv64[SV_LNL / 2];
-                    if (Dm <= 1) e = slip_mul_rows_reg<1>(P, M, Md, wl2, n2, sb);
-                    else if (Dm == 2) e = slip_mul_rows_reg<2>(P, M, Md, wl2, n2, sb);
-                    else if (Dm == 3) e = slip_mul_rows_reg<3>(P, M, Md, wl2, n2, sb);
-                    else e = slip_mul_rows_reg<4>(P, M, Md, wl2, n2, sb);
-                    if (e && lane == 0) sv[SV_ERR] = 1;
-                }
+            const int n2 = *wcnt2;
+            const int64_t sb = sv64[SV_LNL / 2];
+            /* a long list of one-limb rows goes to the helpers as well (one row per wave over 63 CUs) unless they
+             * are busy with this column's division rows; a short one is multiplied here */
+            const int fork3 = !forked && P.fork_min > 0 && n2 >= P.fork_min;
+            if (n2 > 0 && !fork3) {
+                const int e = slip_mul_rows_any(P, k, Md, wl2, wave, nw, n2, sb);
+                if (e && lane == 0) sv[SV_ERR] = 1;
             }
             slip_drain_end(P, lds, forked, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
+            if (fork3 && !sv[SV_ERR]) slip_drain(P, lds, 3, 0, 0, k, sb, n2, wl2, b0, b1, b2);
             SLIP_STAMP(10);
             if (tid == 0) { *wcnt = 0; *wcnt2 = 0; sv64[SV_LALLOC / 2] = (int64_t) lalloc_now; }
             slip_block_sync();
@@ -1266,9 +1289,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     uint32_t *tab = lds + SLIP_LDS_TAB;
     const bool use_tab = npat <= SLIP_TAB_CAP;
     const int64_t Lnl0 = sv64[SV_LNL / 2];              /* L slab cursor at the start of this column */
-    auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[4 * t] : P.row_perm[P.pat[t]]; };
-    auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[4 * t + 1] : P.xrow[P.row_perm[P.pat[t]]].len; };
-    auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[4 * t + 2] : P.xrow[P.row_perm[P.pat[t]]].bits; };
+    auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[4 * t] : P.row_perm[pat_at(t)]; };
+    auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[4 * t + 1] : P.xrow[P.row_perm[pat_at(t)]].len; };
+    auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[4 * t + 2] : P.xrow[P.row_perm[pat_at(t)]].bits; };
     /* where the digits of a row are: its x row, or (rows multiplied straight into L) the slab */
     auto row_digits = [&](int r) -> const dig_t * {
         const dig_t *X = P.xd + (int64_t) r * P.xcap;
@@ -1277,12 +1300,12 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     auto ent_digits = [&](int t) -> const dig_t * {
         if (use_tab) return (tab[4 * t + 3] >> 31) ? (const dig_t *)(P.Llimbs + Lnl0 + (int64_t)(tab[4 * t + 3] & 0x7FFFFFFFu))
                                                   : P.xd + (int64_t) tab[4 * t] * P.xcap;
-        return row_digits(P.row_perm[P.pat[t]]);
+        return row_digits(P.row_perm[pat_at(t)]);
     };
     {
         int mx = 0;
         for (int t = tid; t < npat; t += T) {
-            const int r = P.row_perm[P.pat[t]];
+            const int r = P.row_perm[pat_at(t)];
             const SlipRow xr = P.xrow[r];
             const int l = slip_abs(xr.len);
             if (l > mx) mx = l;
@@ -1677,6 +1700,8 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
     /* x <- x * det (slip_array_mul.c:19), det = rho[n-1] */
     int npat, nUdummy;
     slip_pattern(P, lds, bm, n, &npat, &nUdummy);
+    const int32_t *patl = (const int32_t *)(lds + SLIP_LDS_PAT);
+    auto pat_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? patl[t] : P.pat[t]; };
     slip_block_sync();
     {
         volatile int32_t *wcnt = &sv[SV_CNT0];
@@ -1685,7 +1710,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
         for (int t0 = 0; t0 < npat; t0 += SLIP_WORK_CAP) {
             const int te = t0 + SLIP_WORK_CAP < npat ? t0 + SLIP_WORK_CAP : npat;
             for (int t = t0 + tid; t < te; t += T) {
-                const int r = P.row_perm[P.pat[t]];
+                const int r = P.row_perm[pat_at(t)];
                 const SlipRow xr = P.xrow[r];
                 if (xr.len == 0) continue;
                 slip_u128 y = 0; int ys = 1; int done = 0;

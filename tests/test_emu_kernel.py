@@ -39,3 +39,32 @@ def test_emulated_solve_matches_reference(emu_lib, name, waves, fork_min, nrhs):
     from conftest import GOLDEN, check_solve
     case = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "solve_index.json")))}[name]
     check_solve(case, lib_path=emu_lib, nrhs=nrhs, waves=waves, fork_min=fork_min)
+
+
+def test_emulated_solve_zero_and_unit_rhs(emu_lib):
+    import json
+    import numpy as np
+    import oracle_lib
+    import slip_lu_amd as sl
+    from conftest import GOLDEN, solve_inputs
+    case = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "solve_index.json")))}["solve_test_mat"]
+    n, Ap, Ai, Alen, Alimbs, q, _ = solve_inputs(case)
+    e = np.zeros(n, np.int64); e[2] = 5
+    bs = np.concatenate([np.zeros(n, np.int64), e])
+    f = sl.Factorization(n, Ap, Ai, Alen, Alimbs, q, waves=2, lib_path=emu_lib)
+    try:
+        f.run(0)
+        xlen, xlimbs = f.solve(np.sign(bs).astype(np.int32), np.abs(bs[bs != 0]).astype(np.uint64), nrhs=2)
+        fac = f.download()
+    finally:
+        f.close()
+    x = oracle_lib.bigints(xlen, xlimbs)
+    want, _ = oracle_lib.factorize_and_solve(n, Ap, Ai, Alen, Alimbs, q, e)
+    assert x[:n] == [0] * n and x[n:] == want
+    # the same through a handle built from the downloaded factors (what the SLIP_LU_solve drop-in does)
+    g = sl.Factorization.from_factors(fac, waves=2, lib_path=emu_lib)
+    try:
+        x2 = g.solve(np.sign(bs).astype(np.int32), np.abs(bs[bs != 0]).astype(np.uint64), nrhs=2)
+    finally:
+        g.close()
+    assert oracle_lib.bigints(*x2) == x

@@ -104,3 +104,26 @@ def test_gpu_solve_on_uploaded_factors():
     bad = dict(fac); bad["pinv"] = np.zeros(n, np.int32)
     with pytest.raises(sl.api.SlipError):
         sl.Factorization.from_factors(bad)
+
+
+def test_gpu_solve_edge_cases():
+    """all-zero right-hand sides, a single nonzero, and a factorisation that is not complete"""
+    import slip_lu_amd as sl
+    from conftest import solve_inputs
+    n, Ap, Ai, Alen, Alimbs, q, _ = solve_inputs(CASES["solve_gen_n40"])
+    e3 = np.zeros(n, np.int64); e3[3] = -7
+    bs = np.concatenate([np.zeros(n, np.int64), e3, np.zeros(n, np.int64)])
+    blen = np.sign(bs).astype(np.int32); blimbs = np.abs(bs[bs != 0]).astype(np.uint64)
+    f = sl.Factorization(n, Ap, Ai, Alen, Alimbs, q)
+    try:
+        f.run(n // 2)                                            # columns [0, n/2) only
+        with pytest.raises(sl.api.SlipError):
+            f.solve(blen, blimbs, nrhs=3)
+        f.run(0)
+        xlen, xlimbs = f.solve(blen, blimbs, nrhs=3)
+    finally:
+        f.close()
+    x = oracle_lib.bigints(xlen, xlimbs)
+    assert x[:n] == [0] * n and x[2 * n:] == [0] * n
+    want, _ = oracle_lib.factorize_and_solve(n, Ap, Ai, Alen, Alimbs, q, e3)
+    assert x[n:2 * n] == want
