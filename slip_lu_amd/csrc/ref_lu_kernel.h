@@ -130,7 +130,9 @@ typedef struct SlipState {
 #define SLIP_TAB_CAP       1024
 #define SLIP_PAT_CAP       1024     /* a pattern of at most this many entries stays in LDS               */
 #define SLIP_LDS_PAT       (SLIP_LDS_TAB + 4 * SLIP_TAB_CAP)
-#define SLIP_LDS_BITMAP    (SLIP_LDS_PAT + SLIP_PAT_CAP)
+#define SLIP_LDS_ROWS      (SLIP_LDS_PAT + SLIP_PAT_CAP)     /* row id of every pattern entry (same cap)        */
+#define SLIP_LDS_DIROFF    (SLIP_LDS_ROWS + SLIP_PAT_CAP)    /* slab offset of a row multiplied straight into L */
+#define SLIP_LDS_BITMAP    (SLIP_LDS_DIROFF + SLIP_PAT_CAP)
 
 enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_GEN = 5, SV_LISTN = 6, SV_TMP = 7,
        SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14,
@@ -664,10 +666,14 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
         const int r = (int) recs[5 * t];
         const int32_t xl = (int32_t) recs[5 * t + 3];
         const int64_t off = slab_base + (int64_t) recs[5 * t + 4];
-        WR<D> A = wr_zero<D>();
-        if (lane == 0) A.d[0] = recs[5 * t + 1];
-        if (lane == 1) A.d[0] = recs[5 * t + 2];
-        const WR<D> Y = wr_mul<D>(A, slip_abs(xl), Mr);
+        WR<D> Y;
+        if (slip_abs(xl) == 1) Y = wr_mul_digit<D>(recs[5 * t + 1], Mr);      /* the common case: |a| < 2^32 */
+        else {
+            WR<D> A = wr_zero<D>();
+            if (lane == 0) A.d[0] = recs[5 * t + 1];
+            if (lane == 1) A.d[0] = recs[5 * t + 2];
+            Y = wr_mul<D>(A, slip_abs(xl), Mr);
+        }
         const int len = wr_len<D>(Y);
         wr_store<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
         const uint32_t top = len ? wr_digit<D>(Y, len - 1) : 0u;
@@ -1122,6 +1128,12 @@ SLIP_DEV void slip_pattern(const SlipParams &P, uint32_t *lds, const uint32_t *b
             }
         }
     }
+    /* the rows behind the positions, gathered once for the phases that follow (one parallel round of loads) */
+    if (totA <= SLIP_PAT_CAP) {
+        int32_t *patl = (int32_t *)(lds + SLIP_LDS_PAT), *rowl = (int32_t *)(lds + SLIP_LDS_ROWS);
+        slip_block_sync();
+        for (int t = tid; t < (int) totA; t += T) rowl[t] = P.row_perm[patl[t]];
+    }
     *npat_out = (int) totA; *nU_out = (int) totU_;
 }
 
@@ -1138,6 +1150,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
     const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
     const int col = P.q[k];
+    const int pc_col = P.pinv[col];                     /* position of the "diagonal" row: fixed until this column's swap */
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     volatile int64_t *sv64 = (volatile int64_t *)(lds + SLIP_LDS_VARS);
     uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
@@ -1190,6 +1203,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     const int npat = npat_, nU = nU_, nL = npat - nU;
     const int32_t *patl = (const int32_t *)(lds + SLIP_LDS_PAT);
     auto pat_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? patl[t] : P.pat[t]; };
+    const int32_t *rowl = (const int32_t *)(lds + SLIP_LDS_ROWS);
+    uint32_t *diroff = lds + SLIP_LDS_DIROFF;
+    auto row_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? rowl[t] : P.row_perm[P.pat[t]]; };
     slip_block_sync();
     SLIP_STAMP(2);
 
@@ -1213,7 +1229,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             const int te = t0 + SLIP_WORK_CAP < nL ? t0 + SLIP_WORK_CAP : nL;
             const unsigned long long chunk_base = (unsigned long long) sv64[SV_LALLOC / 2];
             for (int t = t0 + tid; t < te; t += T) {
-                const int r = P.row_perm[pat_at(nU + t)];
+                const int r = row_at(nU + t);
                 const SlipRow xr = P.xrow[r];
                 if (xr.len == 0 || xr.h >= k - 1) continue;
                 int done = 0;
@@ -1229,6 +1245,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                         const int at = slip_atomic_add_i32((int32_t *) wcnt2, 1);
                         wl2[5 * at] = (uint32_t) r; wl2[5 * at + 1] = (uint32_t) xv; wl2[5 * at + 2] = (uint32_t)(xv >> 32);
                         wl2[5 * at + 3] = (uint32_t) xr.len; wl2[5 * at + 4] = (uint32_t)(chunk_base + (unsigned long long) at * slot);
+                        if (npat <= SLIP_PAT_CAP) diroff[nU + t] = wl2[5 * at + 4];
                         done = 1;
                     } else if (xr.h < 0 && lm + 2 <= P.xcap) {
                         /* beyond 256 digits: this lane walks the pivot's digits */
@@ -1268,7 +1285,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             const int64_t sb = sv64[SV_LNL / 2];
             /* a long list of one-limb rows goes to the helpers as well (one row per wave over 63 CUs) unless they
              * are busy with this column's division rows; a short one is multiplied here */
-            const int fork3 = !forked && P.fork_min > 0 && n2 >= P.fork_min;
+            /* (a hand-off costs ~10 us, the price of about 120 rows done here) */
+            const int fork3 = !forked && P.fork_min > 0 && n2 >= 10 * P.fork_min;
             if (n2 > 0 && !fork3) {
                 const int e = slip_mul_rows_any(P, k, Md, wl2, wave, nw, n2, sb);
                 if (e && lane == 0) sv[SV_ERR] = 1;
@@ -1289,9 +1307,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     uint32_t *tab = lds + SLIP_LDS_TAB;
     const bool use_tab = npat <= SLIP_TAB_CAP;
     const int64_t Lnl0 = sv64[SV_LNL / 2];              /* L slab cursor at the start of this column */
-    auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[4 * t] : P.row_perm[pat_at(t)]; };
-    auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[4 * t + 1] : P.xrow[P.row_perm[pat_at(t)]].len; };
-    auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[4 * t + 2] : P.xrow[P.row_perm[pat_at(t)]].bits; };
+    auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[4 * t] : row_at(t); };
+    auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[4 * t + 1] : P.xrow[row_at(t)].len; };
+    auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[4 * t + 2] : P.xrow[row_at(t)].bits; };
     /* where the digits of a row are: its x row, or (rows multiplied straight into L) the slab */
     auto row_digits = [&](int r) -> const dig_t * {
         const dig_t *X = P.xd + (int64_t) r * P.xcap;
@@ -1300,18 +1318,18 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     auto ent_digits = [&](int t) -> const dig_t * {
         if (use_tab) return (tab[4 * t + 3] >> 31) ? (const dig_t *)(P.Llimbs + Lnl0 + (int64_t)(tab[4 * t + 3] & 0x7FFFFFFFu))
                                                   : P.xd + (int64_t) tab[4 * t] * P.xcap;
-        return row_digits(P.row_perm[pat_at(t)]);
+        return row_digits(row_at(t));
     };
     {
         int mx = 0;
         for (int t = tid; t < npat; t += T) {
-            const int r = P.row_perm[pat_at(t)];
+            const int r = row_at(t);
             const SlipRow xr = P.xrow[r];
             const int l = slip_abs(xr.len);
             if (l > mx) mx = l;
             if (use_tab) {
                 tab[4 * t] = (uint32_t) r; tab[4 * t + 1] = (uint32_t) xr.len; tab[4 * t + 2] = (uint32_t) xr.bits;
-                tab[4 * t + 3] = xr.pad ? (0x80000000u | (uint32_t)(*(const int64_t *)(P.xd + (int64_t) r * P.xcap) - Lnl0)) : 0u;
+                tab[4 * t + 3] = xr.pad ? (0x80000000u | diroff[t]) : 0u;      /* use_tab implies the pattern is in LDS */
             }
         }
         if (mx > 0) slip_atomic_max_i32((int32_t *) &sv[SV_MAXDIG], mx);
@@ -1424,7 +1442,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     int pivrow = ent_row(nU + best);
     /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146) */
     if (scheme == 1 || scheme == 3 || scheme == 4) {
-        const int pc = P.pinv[col];
+        const int pc = pc_col;
         const int diag_ok = pc >= k && ((bm[pc >> 5] >> (pc & 31)) & 1u) && P.xrow[col].len != 0;
         if (diag_ok && pivrow != col) {
             int take = 0, err = 0;
@@ -1460,7 +1478,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             if (take) pivrow = col;
         }
     }
-    const int pivpos = P.pinv[pivrow];                /* pre-swap position, >= k */
+    const int pivpos = pivrow == col ? pc_col : pat_at(nU + best);   /* pre-swap position (the pattern holds positions), >= k */
     SLIP_STAMP(4);
 
     /* ---- phase 6: append U(:,k) and L(:,k) (SLIP_LU_factorize.c:226-263) ---- */

@@ -139,6 +139,30 @@ template <int D> SLIP_DEV WR<D> wr_mul(const WR<D> &A, int la, const WR<D> &B)
     return wr_normalise<D>(lo, mid, hi);
 }
 
+/* a * M for a one-digit wave-uniform a (the product must fit 64*D digits): digit c = lo(a*M[c]) + hi(a*M[c-1]) + carry,
+ * one multiply, one DPP shift and one ballot carry-lookahead per chunk */
+template <int D> SLIP_DEV WR<D> wr_mul_digit(uint32_t a, const WR<D> &M)
+{
+    const int lane = slip_lane();
+    WR<D> out;
+    uint32_t cin = 0, hi63 = 0;
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+        const uint64_t p = (uint64_t) a * M.d[r];
+        const uint32_t lo = (uint32_t) p, hi = (uint32_t)(p >> 32);
+        const uint32_t hprev = slip_dpp_shr1(hi, hi63);
+        const uint64_t s = (uint64_t) lo + hprev + (lane == 0 ? cin : 0u);
+        const uint32_t dg = (uint32_t) s, g = (uint32_t)(s >> 32);
+        const uint64_t G = slip_ballot(g != 0), Pm = slip_ballot(dg == 0xFFFFFFFFu);
+        uint32_t cout;
+        const uint64_t A = wb_carry_arrivals(G, Pm, &cout);
+        out.d[r] = dg + (uint32_t)((A >> lane) & 1);
+        hi63 = slip_readlane(hi, 63);
+        cin = cout;
+    }
+    return out;
+}
+
 /* x +/- y modulo B^(64*D) */
 template <int D> SLIP_DEV WR<D> wr_addsub(const WR<D> &x, const WR<D> &y, int sub)
 {

@@ -86,6 +86,10 @@ template <int D> static void reg_inv(const uint32_t *d, int ld, int have, int wa
         wr_store<D>(inv, V, want);
     });
 }
+template <int D> static void reg_mul_digit(uint32_t a, const uint32_t *b, int lb, int W, uint32_t *out)
+{
+    emu::launch(1, 64, [&]() { wr_store<D>(out, wr_mul_digit<D>(a, wr_load<D>(b, lb)), W); });
+}
 template <int D> static int reg_len(const uint32_t *a, int la)
 {
     int r = -1;
@@ -108,6 +112,9 @@ void emu_reg_shr(int D, const uint32_t *a, int la, int shift, int W, uint32_t *o
 void emu_reg_inv(int D, const uint32_t *d, int ld, int have, int want, uint32_t *inv)
 { switch (D) { case 1: reg_inv<1>(d, ld, have, want, inv); break; case 2: reg_inv<2>(d, ld, have, want, inv); break;
                case 3: reg_inv<3>(d, ld, have, want, inv); break; default: reg_inv<4>(d, ld, have, want, inv); } }
+void emu_reg_mul_digit(int D, uint32_t a, const uint32_t *b, int lb, int W, uint32_t *out)
+{ switch (D) { case 1: reg_mul_digit<1>(a, b, lb, W, out); break; case 2: reg_mul_digit<2>(a, b, lb, W, out); break;
+               case 3: reg_mul_digit<3>(a, b, lb, W, out); break; default: reg_mul_digit<4>(a, b, lb, W, out); } }
 int emu_reg_len(int D, const uint32_t *a, int la)
 { switch (D) { case 1: return reg_len<1>(a, la); case 2: return reg_len<2>(a, la); case 3: return reg_len<3>(a, la); default: return reg_len<4>(a, la); } }
 }

@@ -75,3 +75,16 @@ def test_register_primitives(L):
         inv = np.zeros(cap, dtype=np.uint32)
         L.emu_reg_inv(D, P(digs(d, lb)), lb, 0, want, P(inv))
         assert (val(inv, want) * d) % (1 << (32 * want)) == 1
+
+
+def test_register_digit_multiply(L):
+    """wr_mul_digit: one-digit a times a long number (the rows of a column times the previous pivot)"""
+    r = random.Random(3)
+    for _ in range(80):
+        D = r.choice([1, 2, 3, 4]); cap = 64 * D
+        lb = min(r.choice([1, 2, 63, 64, 65, 127, 128, 191, 255]), cap - 1)
+        b = rnd(r, lb, r.randrange(3))
+        a = r.choice([1, 2, 0xFFFFFFFF, 0x80000000, r.getrandbits(32) | 1, r.getrandbits(16) | 1])
+        out = np.zeros(cap, dtype=np.uint32)
+        L.emu_reg_mul_digit(D, C.c_uint32(a), P(digs(b, lb)), lb, cap, P(out))
+        assert val(out, cap) == a * b
