@@ -148,7 +148,7 @@ int slip_hip_wave_op_test(int32_t op, int32_t nops, int32_t la, int32_t lb, int3
 
 /* Diagnostic builds (-DSLIP_PROFILE_PHASES) only: shader cycles thread 0 spent per phase of the
  * column loop during the last run; all zero in the product build. */
-int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out12);
+int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out20);   /* 20 slots */
 
 const char *slip_hip_version(void);
 

@@ -108,7 +108,7 @@ typedef struct SlipState {
     int64_t out_used;                               /* solve: limbs of the output slab in use                              */
     int32_t solve_next, pad32;                      /* solve: next right-hand side                                         */
     unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig;
-    unsigned long long prof[12];                    /* -DSLIP_PROFILE_PHASES builds only */
+    unsigned long long prof[20];                    /* -DSLIP_PROFILE_PHASES builds only */
 } SlipState;
 
 #if defined(SLIP_PROFILE_PHASES) && !defined(SLIP_EMULATE)
@@ -655,35 +655,49 @@ SLIP_DEV uint64_t slip_top64(const dig_t *X, int l)
 
 /* rows[t] (one-limb values, never updated: h < 0) times the long pivot M: the pivot's digits stay in
  * registers, every wave takes rows in turn (slip_REF_triangular_solve.c:248-257 for untouched rows) */
+template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const SlipPiv &M, const WR<D> &Y, int r, int32_t xl, int64_t off)
+{
+    const int len = wr_len<D>(Y);
+    wr_store<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
+    const uint32_t top = len ? wr_digit<D>(Y, len - 1) : 0u;
+    if (slip_lane() == 0) {
+        SlipRow nr; nr.len = (slip_sgn(xl) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = -1;
+        nr.pad = 1;                                          /* the value lives in the L slab ... */
+        nr.bits = len ? 32 * len - slip_clz32(top) : 0;
+        P.xrow[r] = nr;
+        *(int64_t *)(P.xd + (int64_t) r * P.xcap) = off;     /* ... at this limb offset */
+    }
+}
+
 template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, const uint32_t *recs,
                                                 int first, int stride, int nrows, int64_t slab_base)
 {
     const int lane = slip_lane();
     const WR<D> Mr = wr_load<D>(Md, slip_abs(M.len));
-    for (int t = first; t < nrows; t += stride) {
-        /* record written by the classifying lane: row, low/high digit of the one-limb value, signed length,
-         * and the slot of the L slab reserved for the product (these rows ARE L(:,k): no second copy) */
-        const int r = (int) recs[5 * t];
+    /* record written by the classifying lane: row, low/high digit of the one-limb value, signed length,
+     * and the slot of the L slab reserved for the product (these rows ARE L(:,k): no second copy) */
+    int t = first;
+    /* pairs of one-digit rows (|a| < 2^32, the common case): two carry chains side by side */
+    for (; t + stride < nrows; t += 2 * stride) {
+        const int u = t + stride;
+        const int32_t xl0 = (int32_t) recs[5 * t + 3], xl1 = (int32_t) recs[5 * u + 3];
+        if (slip_abs(xl0) != 1 || slip_abs(xl1) != 1) break;
+        WR<D> Y0, Y1;
+        wr_mul_digit2<D>(recs[5 * t + 1], recs[5 * u + 1], Mr, Y0, Y1);
+        slip_mul_row_finish<D>(P, M, Y0, (int) recs[5 * t], xl0, slab_base + (int64_t) recs[5 * t + 4]);
+        slip_mul_row_finish<D>(P, M, Y1, (int) recs[5 * u], xl1, slab_base + (int64_t) recs[5 * u + 4]);
+    }
+    for (; t < nrows; t += stride) {
         const int32_t xl = (int32_t) recs[5 * t + 3];
-        const int64_t off = slab_base + (int64_t) recs[5 * t + 4];
         WR<D> Y;
-        if (slip_abs(xl) == 1) Y = wr_mul_digit<D>(recs[5 * t + 1], Mr);      /* the common case: |a| < 2^32 */
+        if (slip_abs(xl) == 1) Y = wr_mul_digit<D>(recs[5 * t + 1], Mr);      /* |a| < 2^32 */
         else {
             WR<D> A = wr_zero<D>();
             if (lane == 0) A.d[0] = recs[5 * t + 1];
             if (lane == 1) A.d[0] = recs[5 * t + 2];
             Y = wr_mul<D>(A, slip_abs(xl), Mr);
         }
-        const int len = wr_len<D>(Y);
-        wr_store<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
-        const uint32_t top = len ? wr_digit<D>(Y, len - 1) : 0u;
-        if (lane == 0) {
-            SlipRow nr; nr.len = (slip_sgn(xl) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = -1;
-            nr.pad = 1;                                          /* the value lives in the L slab ... */
-            nr.bits = len ? 32 * len - slip_clz32(top) : 0;
-            P.xrow[r] = nr;
-            *(int64_t *)(P.xd + (int64_t) r * P.xcap) = off;     /* ... at this limb offset */
-        }
+        slip_mul_row_finish<D>(P, M, Y, (int) recs[5 * t], xl, slab_base + (int64_t) recs[5 * t + 4]);
     }
     return 0;
 }
@@ -1337,6 +1351,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     }
     const int maxdig = sv[SV_MAXDIG];
     if (P.limb_cap > 0 && ((maxdig + 1) >> 1) > P.limb_cap) return SLIPDEV_WINDOW_END;
+    SLIP_STAMP(12);                                       /* column table built */
 
     /* kind of search: 0 smallest, 1 largest, 2 first nonzero (slip_get_pivot.c:58-155).
      * Lanes order the candidates by (bit length, leading 64 bits); the candidates that tie on
@@ -1439,6 +1454,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             slip_block_sync();
         }
     }
+    SLIP_STAMP(13);                                       /* smallest / largest candidate known */
     int pivrow = ent_row(nU + best);
     /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146) */
     if (scheme == 1 || scheme == 3 || scheme == 4) {
@@ -1566,6 +1582,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         const int lw = (slip_abs(xl) + 1) & ~1;
         for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = srcx[c];
     }
+    SLIP_STAMP(14);                                       /* wave 0 through its share of the copy */
     slip_block_sync();
     SLIP_STAMP(6);
     /* pivot bookkeeping (slip_get_pivot.c:164-182); wave 0 */

@@ -741,7 +741,7 @@ extern "C" double slip_hip_factor_solve_ms(const slip_hip_factor *f) { return f 
 extern "C" int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out12)
 {
     if (!f || !out12) return SLIP_HIP_INCORRECT_INPUT;
-    for (int i = 0; i < 12; i++) out12[i] = f->hs.prof[i];
+    for (int i = 0; i < 20; i++) out12[i] = f->hs.prof[i];
     return SLIP_HIP_OK;
 }
 

@@ -163,6 +163,30 @@ template <int D> SLIP_DEV WR<D> wr_mul_digit(uint32_t a, const WR<D> &M)
     return out;
 }
 
+/* two independent one-digit products against the same M, chunk by chunk side by side: the two carry chains
+ * (DPP shift -> add -> ballots -> scalar look-ahead) overlap instead of running back to back */
+template <int D> SLIP_DEV void wr_mul_digit2(uint32_t a0, uint32_t a1, const WR<D> &M, WR<D> &out0, WR<D> &out1)
+{
+    const int lane = slip_lane();
+    uint32_t cin0 = 0, cin1 = 0, h0 = 0, h1 = 0;
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+        const uint64_t p0 = (uint64_t) a0 * M.d[r], p1 = (uint64_t) a1 * M.d[r];
+        const uint32_t lo0 = (uint32_t) p0, hi0 = (uint32_t)(p0 >> 32), lo1 = (uint32_t) p1, hi1 = (uint32_t)(p1 >> 32);
+        const uint32_t q0 = slip_dpp_shr1(hi0, h0), q1 = slip_dpp_shr1(hi1, h1);
+        const uint64_t s0 = (uint64_t) lo0 + q0 + (lane == 0 ? cin0 : 0u), s1 = (uint64_t) lo1 + q1 + (lane == 0 ? cin1 : 0u);
+        const uint32_t d0 = (uint32_t) s0, g0 = (uint32_t)(s0 >> 32), d1 = (uint32_t) s1, g1 = (uint32_t)(s1 >> 32);
+        const uint64_t G0 = slip_ballot(g0 != 0), P0 = slip_ballot(d0 == 0xFFFFFFFFu);
+        const uint64_t G1 = slip_ballot(g1 != 0), P1 = slip_ballot(d1 == 0xFFFFFFFFu);
+        uint32_t c0, c1;
+        const uint64_t A0 = wb_carry_arrivals(G0, P0, &c0), A1 = wb_carry_arrivals(G1, P1, &c1);
+        out0.d[r] = d0 + (uint32_t)((A0 >> lane) & 1);
+        out1.d[r] = d1 + (uint32_t)((A1 >> lane) & 1);
+        h0 = slip_readlane(hi0, 63); h1 = slip_readlane(hi1, 63);
+        cin0 = c0; cin1 = c1;
+    }
+}
+
 /* x +/- y modulo B^(64*D) */
 template <int D> SLIP_DEV WR<D> wr_addsub(const WR<D> &x, const WR<D> &y, int sub)
 {

@@ -90,6 +90,14 @@ template <int D> static void reg_mul_digit(uint32_t a, const uint32_t *b, int lb
 {
     emu::launch(1, 64, [&]() { wr_store<D>(out, wr_mul_digit<D>(a, wr_load<D>(b, lb)), W); });
 }
+template <int D> static void reg_mul_digit2(uint32_t a0, uint32_t a1, const uint32_t *b, int lb, int W, uint32_t *out0, uint32_t *out1)
+{
+    emu::launch(1, 64, [&]() {
+        WR<D> Y0, Y1;
+        wr_mul_digit2<D>(a0, a1, wr_load<D>(b, lb), Y0, Y1);
+        wr_store<D>(out0, Y0, W); wr_store<D>(out1, Y1, W);
+    });
+}
 template <int D> static int reg_len(const uint32_t *a, int la)
 {
     int r = -1;
@@ -115,6 +123,9 @@ void emu_reg_inv(int D, const uint32_t *d, int ld, int have, int want, uint32_t 
 void emu_reg_mul_digit(int D, uint32_t a, const uint32_t *b, int lb, int W, uint32_t *out)
 { switch (D) { case 1: reg_mul_digit<1>(a, b, lb, W, out); break; case 2: reg_mul_digit<2>(a, b, lb, W, out); break;
                case 3: reg_mul_digit<3>(a, b, lb, W, out); break; default: reg_mul_digit<4>(a, b, lb, W, out); } }
+void emu_reg_mul_digit2(int D, uint32_t a0, uint32_t a1, const uint32_t *b, int lb, int W, uint32_t *out0, uint32_t *out1)
+{ switch (D) { case 1: reg_mul_digit2<1>(a0, a1, b, lb, W, out0, out1); break; case 2: reg_mul_digit2<2>(a0, a1, b, lb, W, out0, out1); break;
+               case 3: reg_mul_digit2<3>(a0, a1, b, lb, W, out0, out1); break; default: reg_mul_digit2<4>(a0, a1, b, lb, W, out0, out1); } }
 int emu_reg_len(int D, const uint32_t *a, int la)
 { switch (D) { case 1: return reg_len<1>(a, la); case 2: return reg_len<2>(a, la); case 3: return reg_len<3>(a, la); default: return reg_len<4>(a, la); } }
 }

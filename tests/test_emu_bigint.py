@@ -88,3 +88,6 @@ def test_register_digit_multiply(L):
         out = np.zeros(cap, dtype=np.uint32)
         L.emu_reg_mul_digit(D, C.c_uint32(a), P(digs(b, lb)), lb, cap, P(out))
         assert val(out, cap) == a * b
+        a2 = r.choice([1, 0xFFFFFFFF, r.getrandbits(32) | 1]); out2 = np.zeros(cap, dtype=np.uint32)
+        L.emu_reg_mul_digit2(D, C.c_uint32(a), C.c_uint32(a2), P(digs(b, lb)), lb, cap, P(out), P(out2))
+        assert val(out, cap) == a * b and val(out2, cap) == a2 * b
