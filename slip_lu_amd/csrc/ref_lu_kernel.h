@@ -75,6 +75,7 @@ typedef struct SlipParams {
     int32_t seq0, pad1;                             /* hand-off generation at launch (SlipState.seq)          */
     int32_t bitmap_in_lds, scratch_in_lds;          /* where the bitmap / wave scratch live (generic kernel)  */
     int32_t *dbg;                                   /* 4 words per workgroup: hand-off diagnostics            */
+    const struct SlipParams *self;                  /* device copy of this struct: what out-of-line routines read */
 } SlipParams;
 
 /* one published batch of wave-level work (HBM; handed over with agent-scope release/acquire).
@@ -132,7 +133,9 @@ typedef struct SlipState {
 #define SLIP_LDS_PAT       (SLIP_LDS_TAB + 4 * SLIP_TAB_CAP)
 #define SLIP_LDS_ROWS      (SLIP_LDS_PAT + SLIP_PAT_CAP)     /* row id of every pattern entry (same cap)        */
 #define SLIP_LDS_DIROFF    (SLIP_LDS_ROWS + SLIP_PAT_CAP)    /* slab offset of a row multiplied straight into L */
-#define SLIP_LDS_BITMAP    (SLIP_LDS_DIROFF + SLIP_PAT_CAP)
+#define SLIP_LDS_KEYS      (SLIP_LDS_DIROFF + SLIP_PAT_CAP)  /* leading 64 bits of a row multiplied straight into L */
+#define SLIP_LDS_TODO      (SLIP_LDS_KEYS + 2 * SLIP_PAT_CAP) /* batch planning: (pivot, digits) requests         */
+#define SLIP_LDS_BITMAP    (SLIP_LDS_TODO + 2 * SLIP_WORK_CAP)
 
 enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_GEN = 5, SV_LISTN = 6, SV_TMP = 7,
        SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14,
@@ -655,22 +658,41 @@ SLIP_DEV uint64_t slip_top64(const dig_t *X, int l)
 
 /* rows[t] (one-limb values, never updated: h < 0) times the long pivot M: the pivot's digits stay in
  * registers, every wave takes rows in turn (slip_REF_triangular_solve.c:248-257 for untouched rows) */
-template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const SlipPiv &M, const WR<D> &Y, int r, int32_t xl, int64_t off)
+/* rec3: word 3 of the row's record = (pattern index << 3) | (negative << 2) | digits of the one-limb value;
+ * ctab != null (the master's own LDS): also enter the row into the column table and its leading 64 bits into the key
+ * list, so that the pivot search does not read back through memory what this CU has just produced */
+template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const SlipPiv &M, const WR<D> &Y, int r, uint32_t rec3, int64_t off,
+                                                   uint32_t slot_off, uint32_t *ctab, uint32_t *ckeys)
 {
     const int len = wr_len<D>(Y);
     wr_store<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
-    const uint32_t top = len ? wr_digit<D>(Y, len - 1) : 0u;
+    const uint32_t d1 = len ? wr_digit<D>(Y, len - 1) : 0u;
+    const int neg = (int)((rec3 >> 2) & 1u) ^ (M.len < 0);
+    const int32_t slen = neg ? -len : len;
+    const int bits = len ? 32 * len - slip_clz32(d1) : 0;
+    if (ctab) {
+        const uint32_t d2 = len >= 2 ? wr_digit<D>(Y, len - 2) : 0u, d3 = len >= 3 ? wr_digit<D>(Y, len - 3) : 0u;
+        if (slip_lane() == 0) {
+            uint64_t top = ((uint64_t) d1 << 32) | d2;
+            const int sh = len ? slip_clz32(d1) : 0;
+            if (sh) top = (top << sh) | (uint64_t)(d3 >> (32 - sh));
+            const int pidx = (int)(rec3 >> 3);
+            ctab[4 * pidx] = (uint32_t) r; ctab[4 * pidx + 1] = (uint32_t) slen; ctab[4 * pidx + 2] = (uint32_t) bits;
+            ctab[4 * pidx + 3] = 0x80000000u | slot_off;
+            ckeys[2 * pidx] = (uint32_t) top; ckeys[2 * pidx + 1] = (uint32_t)(top >> 32);
+        }
+    }
     if (slip_lane() == 0) {
-        SlipRow nr; nr.len = (slip_sgn(xl) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = -1;
+        SlipRow nr; nr.len = slen; nr.h = -1;
         nr.pad = 1;                                          /* the value lives in the L slab ... */
-        nr.bits = len ? 32 * len - slip_clz32(top) : 0;
+        nr.bits = bits;
         P.xrow[r] = nr;
         *(int64_t *)(P.xd + (int64_t) r * P.xcap) = off;     /* ... at this limb offset */
     }
 }
 
 template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, const uint32_t *recs,
-                                                int first, int stride, int nrows, int64_t slab_base)
+                                                int first, int stride, int nrows, int64_t slab_base, uint32_t *ctab, uint32_t *ckeys)
 {
     const int lane = slip_lane();
     const WR<D> Mr = wr_load<D>(Md, slip_abs(M.len));
@@ -680,24 +702,24 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
     /* pairs of one-digit rows (|a| < 2^32, the common case): two carry chains side by side */
     for (; t + stride < nrows; t += 2 * stride) {
         const int u = t + stride;
-        const int32_t xl0 = (int32_t) recs[5 * t + 3], xl1 = (int32_t) recs[5 * u + 3];
-        if (slip_abs(xl0) != 1 || slip_abs(xl1) != 1) break;
+        const uint32_t w0 = recs[5 * t + 3], w1 = recs[5 * u + 3];
+        if ((w0 & 3u) != 1u || (w1 & 3u) != 1u) break;
         WR<D> Y0, Y1;
         wr_mul_digit2<D>(recs[5 * t + 1], recs[5 * u + 1], Mr, Y0, Y1);
-        slip_mul_row_finish<D>(P, M, Y0, (int) recs[5 * t], xl0, slab_base + (int64_t) recs[5 * t + 4]);
-        slip_mul_row_finish<D>(P, M, Y1, (int) recs[5 * u], xl1, slab_base + (int64_t) recs[5 * u + 4]);
+        slip_mul_row_finish<D>(P, M, Y0, (int) recs[5 * t], w0, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys);
+        slip_mul_row_finish<D>(P, M, Y1, (int) recs[5 * u], w1, slab_base + (int64_t) recs[5 * u + 4], recs[5 * u + 4], ctab, ckeys);
     }
     for (; t < nrows; t += stride) {
-        const int32_t xl = (int32_t) recs[5 * t + 3];
+        const uint32_t w = recs[5 * t + 3];
         WR<D> Y;
-        if (slip_abs(xl) == 1) Y = wr_mul_digit<D>(recs[5 * t + 1], Mr);      /* |a| < 2^32 */
+        if ((w & 3u) == 1u) Y = wr_mul_digit<D>(recs[5 * t + 1], Mr);      /* |a| < 2^32 */
         else {
             WR<D> A = wr_zero<D>();
             if (lane == 0) A.d[0] = recs[5 * t + 1];
             if (lane == 1) A.d[0] = recs[5 * t + 2];
-            Y = wr_mul<D>(A, slip_abs(xl), Mr);
+            Y = wr_mul<D>(A, (int)(w & 3u), Mr);
         }
-        slip_mul_row_finish<D>(P, M, Y, (int) recs[5 * t], xl, slab_base + (int64_t) recs[5 * t + 4]);
+        slip_mul_row_finish<D>(P, M, Y, (int) recs[5 * t], w, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys);
     }
     return 0;
 }
@@ -705,15 +727,15 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
 /* rows [first, first+stride, ...) of a column's one-limb-times-pivot list (5-word records), pivot rho[k-1];
  * Md: staged copy of the pivot's digits, or null to read them from the L slab */
 SLIP_DEV int slip_mul_rows_any(const SlipParams &P, int k, const dig_t *Md, const uint32_t *recs, int first, int stride, int nrows,
-                               int64_t slab_base)
+                               int64_t slab_base, uint32_t *ctab = (uint32_t *) 0, uint32_t *ckeys = (uint32_t *) 0)
 {
     const SlipPiv M = P.piv[k - 1];
     if (!Md) Md = slip_piv_digits(P, M);
     const int Dm = (slip_abs(M.len) + 2 + 63) >> 6;
-    if (Dm <= 1) return slip_mul_rows_reg<1>(P, M, Md, recs, first, stride, nrows, slab_base);
-    if (Dm == 2) return slip_mul_rows_reg<2>(P, M, Md, recs, first, stride, nrows, slab_base);
-    if (Dm == 3) return slip_mul_rows_reg<3>(P, M, Md, recs, first, stride, nrows, slab_base);
-    return slip_mul_rows_reg<4>(P, M, Md, recs, first, stride, nrows, slab_base);
+    if (Dm <= 1) return slip_mul_rows_reg<1>(P, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
+    if (Dm == 2) return slip_mul_rows_reg<2>(P, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
+    if (Dm == 3) return slip_mul_rows_reg<3>(P, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
+    return slip_mul_rows_reg<4>(P, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
 }
 
 /* ------------------------------------------------------------------ */
@@ -774,6 +796,52 @@ SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, 
     return slip_history_wave(P, r, k - 1, P.xrow[r].h, b0, b1, b2, mode, publish);
 }
 
+/* ---- out-of-line entry points (one copy each; they read the parameters from the device copy) ---- */
+SLIP_DEVN int slip_run_item_out(const SlipParams *Pg, int kind, int j, int jn, int k, int64_t m0, const uint32_t *items, int t,
+                                dig_t *b0, dig_t *b1, dig_t *b2, int mode, int publish)
+{
+    return slip_run_item(*Pg, kind, j, jn, k, m0, items, t, b0, b1, b2, mode, publish);
+}
+SLIP_DEVN int slip_history_wave_out(const SlipParams *Pg, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    return slip_history_wave(*Pg, r, pm, pd, b0, b1, b2);
+}
+SLIP_DEVN int slip_ensure_inv_out(const SlipParams *Pg, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    return slip_ensure_inv_any(*Pg, p, want, b0, b1, b2);
+}
+/* (the few parameters it needs travel by value: no reads through the device copy on the per-column path) */
+SLIP_DEVN int slip_mul_rows_out(uint64_t *Llimbs, SlipRow *xrow, dig_t *xd, int32_t xcap, SlipPiv M, const dig_t *Md, const uint32_t *recs,
+                                int first, int stride, int nrows, int64_t slab_base, uint32_t *ctab, uint32_t *ckeys)
+{
+    SlipParams Pl;
+    Pl.Llimbs = Llimbs; Pl.xrow = xrow; Pl.xd = xd; Pl.xcap = xcap;
+    const int Dm = (slip_abs(M.len) + 2 + 63) >> 6;
+    if (Dm <= 1) return slip_mul_rows_reg<1>(Pl, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
+    if (Dm == 2) return slip_mul_rows_reg<2>(Pl, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
+    if (Dm == 3) return slip_mul_rows_reg<3>(Pl, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
+    return slip_mul_rows_reg<4>(Pl, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
+}
+SLIP_DEVN int slip_divexact_out(const SlipParams *Pg, int r, int p, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    return slip_divexact_wave(*Pg, r, p, b0, b1, b2, 0, 1);
+}
+/* the exact tolerance test of the diagonal preference: |num| * 2^(-te) >= tol_m * |den|  (slip_get_pivot.c:89-118) */
+SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int ln, const dig_t *den, int ldn,
+                                   dig_t *b0, dig_t *b1, dig_t *b2, int wcap)     /* 1 / 0, or -1: scratch too small */
+{
+    int err_ = 0, *err = &err_;
+    const int Wm = ldn + 2;
+    if (slip_lane() == 0) { b2[0] = (uint32_t) tol_m; b2[1] = (uint32_t)(tol_m >> 32); }
+    slip_wave_sync();
+    wb_mul_lo(b0, b2, 2, den, ldn, Wm);
+    const int lm_ = wb_len(b0, Wm);
+    for (int c = slip_lane(); c < lm_; c += SLIP_WAVE) b2[c] = b0[c];
+    slip_wave_sync();
+    const int ge = slip_ge_shifted(num, ln, te < 0 ? -te : 0, b2, lm_, te > 0 ? te : 0, b0, b1, wcap, err);
+    return err_ ? -1 : ge;
+}
+
 /* planning helper, called by every lane of a wave: the lanes with a request (pivot h to W digits) that name the
  * same pivot reduce to one list entry carrying the largest width */
 SLIP_DEV void slip_plan_push(volatile int32_t *sv, uint32_t *todo, int has, int h, int W)
@@ -810,7 +878,7 @@ SLIP_DEV int slip_drain_begin(const SlipParams &P, uint32_t *lds, int kind, int 
      *    which cached inverses the item divides by and to how many digits (the same width rules the performing
      *    wave applies): 1/rho[jn-1] and 1/rho[jn] are common to a source's updates and reduce to two maxima,
      *    the history divisors that are not long enough yet go on a list; then one wave per inverse extends it. */
-    uint32_t *todo = lds + SLIP_LDS_TAB;      /* the column table is not live while batches run */
+    uint32_t *todo = lds + SLIP_LDS_TODO;
     if (tid == 0) { sv[SV_PLAN_D] = 0; sv[SV_PLAN_R] = 0; sv[SV_PLAN_N] = 0; }
     slip_block_sync();
     if (kind == 1 || kind == 2)
@@ -839,10 +907,10 @@ SLIP_DEV int slip_drain_begin(const SlipParams &P, uint32_t *lds, int kind, int 
     {
         const int wd = sv[SV_PLAN_D], wr = sv[SV_PLAN_R], ntodo = sv[SV_PLAN_N];
         int e = 0;
-        if (wd > 0 && wave == 0) e = slip_ensure_inv_any(P, jn - 1, wd, b0, b1, b2);
-        if (!e && wr > 0 && wave == 1 % nw) e = slip_ensure_inv_any(P, jn, wr, b0, b1, b2);
+        if (wd > 0 && wave == 0) e = slip_ensure_inv_out(P.self, jn - 1, wd, b0, b1, b2);
+        if (!e && wr > 0 && wave == 1 % nw) e = slip_ensure_inv_out(P.self, jn, wr, b0, b1, b2);
         for (int t = (wave + nw - (2 % nw)) % nw; !e && t < ntodo; t += nw)
-            e = slip_ensure_inv_any(P, (int) todo[2 * t], (int) todo[2 * t + 1], b0, b1, b2);
+            e = slip_ensure_inv_out(P.self, (int) todo[2 * t], (int) todo[2 * t + 1], b0, b1, b2);
         if (e && lane == 0) sv[SV_ERR] = e;
     }
     slip_block_sync();
@@ -874,7 +942,7 @@ SLIP_DEV void slip_drain_end(const SlipParams &P, uint32_t *lds, int forked, int
     if (!forked) {
         if (!sv[SV_ERR])
             for (int t = wave; t < nq; t += nw) {
-                const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 1);
+                const int e = slip_run_item_out(P.self, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 1);
                 if (e && lane == 0) sv[SV_ERR] = e;
             }
         slip_block_sync();
@@ -886,7 +954,7 @@ SLIP_DEV void slip_drain_end(const SlipParams &P, uint32_t *lds, int forked, int
      *    without helpers (tests) it does the published batch itself */
     if (H == 0)
         for (int t = wave; t < nq; t += nw) {
-            const int e = slip_run_item(P, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 0);
+            const int e = slip_run_item_out(P.self, kind, j, jn, k, m0, wl, t, b0, b1, b2, 0, 0);
             if (e && lane == 0) sv[SV_ERR] = e == 2 ? 7 : e;
         }
     /* 4. wait for the helpers, then acquire what they wrote */
@@ -956,7 +1024,7 @@ SLIP_DEV void slip_helper_loop(const SlipParams &P, const SlipState *st, uint32_
         /* item t -> workgroup t mod H first: a short batch spreads one wave per CU (a wave alone on its SIMD
          * multiplies at full rate) instead of filling the first few workgroups */
         for (int t = (slip_block() - 1) + wave * H; t < nitems; t += nw * H) {
-            const int e = slip_run_item(P, kind, j, jn, k, m0, P.batch_items, t, b0, b1, b2, 0, 0);
+            const int e = slip_run_item_out(P.self, kind, j, jn, k, m0, P.batch_items, t, b0, b1, b2, 0, 0);
             if (e && lane == 0) sv[SV_ERR] = e == 2 ? 8 : 1;      /* 1: a buffer is too small (the host grows it) */
         }
         slip_vm_drain();
@@ -1019,7 +1087,7 @@ SLIP_DEV void slip_sweep(const SlipParams &P, const int k, uint32_t *lds, uint32
                 } else {
                     slip_block_sync();
                     if (wave == 0) {
-                        if (slip_history_wave(P, j, jn - 1, xj.h, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
+                        if (slip_history_wave_out(P.self, j, jn - 1, xj.h, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
                     }
                     slip_block_sync();
                     xj = P.xrow[j];
@@ -1224,6 +1292,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     SLIP_STAMP(2);
 
     /* ---- phase 4: history update of the non-pivotal rows to level k-1 (:248-257) ---- */
+    /* rows multiplied straight into the L slab by this workgroup enter the column table (and the key list of the
+     * pivot search) from registers; diroff[] marks them (all-ones: not such a row) */
+    int prefill_ok = k >= 1 && npat <= SLIP_PAT_CAP;
+    uint32_t *ctab = lds + SLIP_LDS_TAB, *ckeys = lds + SLIP_LDS_KEYS;
     if (k >= 1) {
         volatile int32_t *wcnt = &sv[SV_CNT0], *wcnt2 = &sv[SV_CNT0 + 1];
         if (tid == 0) { *wcnt = 0; *wcnt2 = 0; }
@@ -1245,6 +1317,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             for (int t = t0 + tid; t < te; t += T) {
                 const int r = row_at(nU + t);
                 const SlipRow xr = P.xrow[r];
+                if (npat <= SLIP_PAT_CAP) diroff[nU + t] = 0xFFFFFFFFu;
                 if (xr.len == 0 || xr.h >= k - 1) continue;
                 int done = 0;
                 if (slip_abs(xr.len) <= 2) {
@@ -1252,13 +1325,22 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                     slip_u128 y = 0; int ys = 1;
                     if (slip_history_small(P, xr, xv, k - 1, xr.h, &y, &ys)) {
                         slip_store_small(P, r, y, ys, xr.h);
+                        if (npat <= SLIP_PAT_CAP) {          /* the lane has the value: table entry and pivot key from registers */
+                            const int yb = slip_bits128(y), yl = (yb + 31) >> 5, pidx = nU + t;
+                            ctab[4 * pidx] = (uint32_t) r; ctab[4 * pidx + 1] = (uint32_t)(ys < 0 ? -yl : yl);
+                            ctab[4 * pidx + 2] = (uint32_t) yb; ctab[4 * pidx + 3] = 0u;
+                            const uint64_t top = yb ? (uint64_t)((y << (128 - yb)) >> 64) : 0ull;
+                            ckeys[2 * pidx] = (uint32_t) top; ckeys[2 * pidx + 1] = (uint32_t)(top >> 32);
+                            diroff[pidx] = 0x7FFFFFFFu;      /* entered, value in its x row */
+                        }
                         done = 1;
                     } else if (xr.h < 0 && lm + 2 <= P.xcap && lm + 2 <= 256) {
                         /* one limb times a long pivot, no division: wave path with the pivot in registers */
                         /* every such row gets a slot of (lm+3)/2 limbs in the L slab (the product has at most lm+2 digits) */
                         const int at = slip_atomic_add_i32((int32_t *) wcnt2, 1);
                         wl2[5 * at] = (uint32_t) r; wl2[5 * at + 1] = (uint32_t) xv; wl2[5 * at + 2] = (uint32_t)(xv >> 32);
-                        wl2[5 * at + 3] = (uint32_t) xr.len; wl2[5 * at + 4] = (uint32_t)(chunk_base + (unsigned long long) at * slot);
+                        wl2[5 * at + 3] = ((uint32_t)(nU + t) << 3) | (xr.len < 0 ? 4u : 0u) | (uint32_t) slip_abs(xr.len);
+                        wl2[5 * at + 4] = (uint32_t)(chunk_base + (unsigned long long) at * slot);
                         if (npat <= SLIP_PAT_CAP) diroff[nU + t] = wl2[5 * at + 4];
                         done = 1;
                     } else if (xr.h < 0 && lm + 2 <= P.xcap) {
@@ -1301,8 +1383,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
              * are busy with this column's division rows; a short one is multiplied here */
             /* (a hand-off costs ~10 us, the price of about 120 rows done here) */
             const int fork3 = !forked && P.fork_min > 0 && n2 >= 10 * P.fork_min;
+            if (fork3) prefill_ok = 0;                       /* helpers cannot write this CU's LDS */
             if (n2 > 0 && !fork3) {
-                const int e = slip_mul_rows_any(P, k, Md, wl2, wave, nw, n2, sb);
+                const int e = slip_mul_rows_out(P.Llimbs, P.xrow, P.xd, P.xcap, M, Md, wl2, wave, nw, n2, sb, prefill_ok ? ctab : (uint32_t *) 0, ckeys);
                 if (e && lane == 0) sv[SV_ERR] = 1;
             }
             slip_drain_end(P, lds, forked, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
@@ -1337,6 +1420,11 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     {
         int mx = 0;
         for (int t = tid; t < npat; t += T) {
+            if (prefill_ok && t >= nU && diroff[t] != 0xFFFFFFFFu) {     /* entered by the multiplying wave */
+                const int l = slip_abs((int32_t) tab[4 * t + 1]);
+                if (l > mx) mx = l;
+                continue;
+            }
             const int r = row_at(t);
             const SlipRow xr = P.xrow[r];
             const int l = slip_abs(xr.len);
@@ -1365,7 +1453,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         auto key_of = [&](int t) -> uint64_t {
             const int32_t xl = ent_len(nU + t);
             if (xl == 0) return ~0ull;
-            const uint64_t v = ((uint64_t) ent_bits(nU + t) << 40) | (slip_top64(ent_digits(nU + t), slip_abs(xl)) >> 24);
+            const bool pre = prefill_ok && diroff[nU + t] != 0xFFFFFFFFu;
+            const uint64_t top = pre ? ((uint64_t) ckeys[2 * (nU + t)] | ((uint64_t) ckeys[2 * (nU + t) + 1] << 32))
+                                     : slip_top64(ent_digits(nU + t), slip_abs(xl));
+            const uint64_t v = ((uint64_t) ent_bits(nU + t) << 40) | (top >> 24);
             return kind == 0 ? v : ~v;
         };
         uint64_t mykey = ~0ull, k1 = ~0ull;
@@ -1479,16 +1570,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                 if (bnum_ < 52 + bden_) take = 0;
                 else if (bnum_ > 53 + bden_) take = 1;
                 else if (Wm > wcap) err = 1;
-                else {
-                    if (lane == 0) { b2[0] = (uint32_t) P.tol_m; b2[1] = (uint32_t)(P.tol_m >> 32); }
-                    slip_wave_sync();
-                    wb_mul_lo(b0, b2, 2, den, ldn, Wm);
-                    const int lm_ = wb_len(b0, Wm);
-                    for (int c = lane; c < lm_; c += SLIP_WAVE) b2[c] = b0[c];
-                    slip_wave_sync();
-                    const int te = P.tol_e;
-                    take = slip_ge_shifted(num, ln, te < 0 ? -te : 0, b2, lm_, te > 0 ? te : 0, b0, b1, wcap, &err);
-                }
+                else { const int tk = slip_tol_compare_out(P.tol_m, P.tol_e, num, ln, den, ldn, b0, b1, b2, wcap); if (tk < 0) err = 1; else take = tk; }
             }
             if (err) return SLIPDEV_GROW_X;
             if (take) pivrow = col;
@@ -1510,6 +1592,19 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         for (int t = tid; t < nL; t += T) if (ent_row(nU + t) == pivrow) sv[SV_TMP] = nU + t;
         slip_block_sync();
         pividx = sv[SV_TMP];
+    }
+    /* the pivot's digits also go to U(:,k): the wave that copies them starts the loads now, the scans below hide them */
+    uint32_t pvd[4] = {0u, 0u, 0u, 0u};
+    int pv_ok = 0;
+    if (use_tab && wave == nU % nw) {
+        const int lwp = (slip_abs((int32_t) tab[4 * pividx + 1]) + 1) & ~1;
+        if (lwp <= 4 * SLIP_WAVE) {
+            const dig_t *src = (tab[4 * pividx + 3] >> 31) ? (const dig_t *)(P.Llimbs + Lnl + (int64_t)(tab[4 * pividx + 3] & 0x7FFFFFFFu))
+                                                          : P.xd + (int64_t) tab[4 * pividx] * P.xcap;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) { const int c = SLIP_WAVE * qd + lane; pvd[qd] = c < lwp ? src[c] : 0u; }
+            pv_ok = 1;
+        }
     }
     /* rows multiplied straight into the L slab (phase 4) already own the first `lalloc` limbs behind Lnl;
      * the other L rows are copied behind them */
@@ -1564,6 +1659,12 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             srcx = (tab[4 * pt + 3] >> 31) ? (const dig_t *)(P.Llimbs + Lnl + (int64_t)(tab[4 * pt + 3] & 0x7FFFFFFFu))
                                            : P.xd + (int64_t) tab[4 * pt] * P.xcap;
             dst = (dig_t *)(P.Ulimbs + Unl + (int64_t) work[e]);
+            if (e == nU && pv_ok) {
+                const int lwp = (slip_abs(xl) + 1) & ~1;
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) { const int c = SLIP_WAVE * qd + lane; if (c < lwp) dst[c] = pvd[qd]; }
+                continue;
+            }
         } else if (use_tab) {
             const int pt = e - 1;
             if (tab[4 * pt + 3] >> 31) continue;                 /* multiplied straight into the slab */
@@ -1783,7 +1884,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
                 if (tid == 0) slip_store_small(P, j, y, slip_sgn(xj.len) * slip_sgn(Dj.len), xj.h);
             } else {
                 slip_block_sync();
-                if (wave == 0) { const int e = slip_divexact_wave(P, j, jp, b0, b1, b2, 0, 1); if (e && lane == 0) sv[SV_ERR] = e; }
+                if (wave == 0) { const int e = slip_divexact_out(P.self, j, jp, b0, b1, b2); if (e && lane == 0) sv[SV_ERR] = e; }
             }
             slip_block_sync();
             if (sv[SV_ERR]) break;

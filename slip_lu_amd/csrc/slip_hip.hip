@@ -141,6 +141,7 @@ struct slip_hip_factor {
     SlipParams P;         /* kernel arguments (device pointers inside)   */
     SlipState hs;         /* host mirror of the mutable device state     */
     SlipState *ds;        /* device copy the kernel works on             */
+    SlipParams *dP;       /* device copy of P (P.self): read by the out-of-line device routines */
     int32_t n; int64_t annz, alimbs;
     int32_t waves, lds_words, bitmap_in_lds, scratch_in_lds;
     int32_t last_status, window_end, launches;
@@ -263,7 +264,7 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
     hipFree(P->Lp); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
     hipFree(P->Up); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
     hipFree(P->pat); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->batch); hipFree(P->batch_items); hipFree(P->dbg);
-    hipFree(f->ds);
+    hipFree(f->ds); hipFree(f->dP);
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
     free(f);
@@ -379,7 +380,7 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
     A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, P->Ucap_nz)); A_(dev_alloc(&P->Ue, P->Ucap_nz));
     A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
-    A_(dev_alloc(&f->ds, 1));
+    A_(dev_alloc(&f->ds, 1)); A_(dev_alloc(&f->dP, 1));
     if (!rc) rc = alloc_x(f, xcap0);
 #undef A_
     if (!rc) {
@@ -422,14 +423,23 @@ static int grow_x_keep(slip_hip_factor *f, int64_t xcap, int32_t K)
     return e;
 }
 
+/* the kernel gets P by value; the out-of-line device routines read the same values through P.self */
+static int upload_params(slip_hip_factor *f, hipStream_t stream)
+{
+    f->P.self = f->dP;
+    CK(hipMemcpyAsync(f->dP, &f->P, sizeof(SlipParams), hipMemcpyHostToDevice, stream));
+    return 0;
+}
+
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
     f->P.seq0 = f->hs.seq;
+    f->P.bitmap_in_lds = f->bitmap_in_lds; f->P.scratch_in_lds = f->scratch_in_lds;
+    { const int e = upload_params(f, stream); if (e) return e; }
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;
     const dim3 grid(1 + f->P.nhelpers), block(64 * f->waves);
-    f->P.bitmap_in_lds = f->bitmap_in_lds; f->P.scratch_in_lds = f->scratch_in_lds;
 #define SLIP_LAUNCH(FAST) do { \
         CK(hipFuncSetAttribute((const void *) slip_factor_kernel<FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes)); \
         hipLaunchKernelGGL((slip_factor_kernel<FAST>), grid, block, lds_bytes, stream, f->P, f->ds); } while (0)
@@ -592,7 +602,7 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     A_(dev_alloc(&P->batch, 1)); A_(dev_alloc(&P->batch_items, SLIP_WORK_WORDS)); A_(dev_alloc(&P->dbg, 4 * 256));
     A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Li, lnz)); A_(dev_alloc(&P->Le, lnz)); A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
     A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, unz)); A_(dev_alloc(&P->Ue, unz)); A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
-    A_(dev_alloc(&f->ds, 1));
+    A_(dev_alloc(&f->ds, 1)); A_(dev_alloc(&f->dP, 1));
     if (!rc && (hipMemset(P->dbg, 0, 4 * 256 * 4) != hipSuccess || hipMemset(P->batch, 0, sizeof(SlipBatch)) != hipSuccess ||
                 hipMemset(P->xrow, 0, (size_t) n * sizeof(SlipRow)) != hipSuccess)) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc) rc = alloc_x(f, 2 * maxdig + 8);                 /* clears piv: upload the records afterwards */
@@ -620,6 +630,7 @@ static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, hipStream_t 
 {
     f->P.seq0 = f->hs.seq;
     f->P.bitmap_in_lds = f->bitmap_in_lds; f->P.scratch_in_lds = f->scratch_in_lds;
+    { const int e = upload_params(f, stream); if (e) return e; }
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;

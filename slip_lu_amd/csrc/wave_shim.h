@@ -20,6 +20,7 @@
 /* ------------------------------------------------------------------ */
 #include "fiber_emu.h"          /* tests/emu */
 #define SLIP_DEV static inline
+#define SLIP_DEVN static __attribute__((noinline))
 #define SLIP_SHARED static
 #define SLIP_KERNEL
 
@@ -75,6 +76,9 @@ static inline int slip_popc64(uint64_t v) { return __builtin_popcountll(v); }
 /* ------------------------------------------------------------------ */
 #include <hip/hip_runtime.h>
 #define SLIP_DEV __device__ __forceinline__
+/* out-of-line device function: ONE copy of a heavy wave-level routine instead of one per call site (the column loop
+ * has to fit the 64 KB instruction cache) */
+#define SLIP_DEVN __device__ __attribute__((noinline))
 #define SLIP_SHARED __shared__
 #define SLIP_KERNEL __global__
 
