@@ -810,18 +810,6 @@ SLIP_DEVN int slip_ensure_inv_out(const SlipParams *Pg, int p, int want, dig_t *
 {
     return slip_ensure_inv_any(*Pg, p, want, b0, b1, b2);
 }
-/* (the few parameters it needs travel by value: no reads through the device copy on the per-column path) */
-SLIP_DEVN int slip_mul_rows_out(uint64_t *Llimbs, SlipRow *xrow, dig_t *xd, int32_t xcap, SlipPiv M, const dig_t *Md, const uint32_t *recs,
-                                int first, int stride, int nrows, int64_t slab_base, uint32_t *ctab, uint32_t *ckeys)
-{
-    SlipParams Pl;
-    Pl.Llimbs = Llimbs; Pl.xrow = xrow; Pl.xd = xd; Pl.xcap = xcap;
-    const int Dm = (slip_abs(M.len) + 2 + 63) >> 6;
-    if (Dm <= 1) return slip_mul_rows_reg<1>(Pl, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
-    if (Dm == 2) return slip_mul_rows_reg<2>(Pl, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
-    if (Dm == 3) return slip_mul_rows_reg<3>(Pl, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
-    return slip_mul_rows_reg<4>(Pl, M, Md, recs, first, stride, nrows, slab_base, ctab, ckeys);
-}
 SLIP_DEVN int slip_divexact_out(const SlipParams *Pg, int r, int p, dig_t *b0, dig_t *b1, dig_t *b2)
 {
     return slip_divexact_wave(*Pg, r, p, b0, b1, b2, 0, 1);
@@ -1292,8 +1280,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     SLIP_STAMP(2);
 
     /* ---- phase 4: history update of the non-pivotal rows to level k-1 (:248-257) ---- */
-    /* rows multiplied straight into the L slab by this workgroup enter the column table (and the key list of the
-     * pivot search) from registers; diroff[] marks them (all-ones: not such a row) */
+    /* one-limb rows finished by a lane enter the column table (and the key list of the pivot search) from that lane's
+     * registers (diroff[] = 0x7FFFFFFF); for rows multiplied straight into the L slab diroff[] holds the slab offset;
+     * all-ones: neither */
     int prefill_ok = k >= 1 && npat <= SLIP_PAT_CAP;
     uint32_t *ctab = lds + SLIP_LDS_TAB, *ckeys = lds + SLIP_LDS_KEYS;
     if (k >= 1) {
@@ -1385,7 +1374,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             const int fork3 = !forked && P.fork_min > 0 && n2 >= 10 * P.fork_min;
             if (fork3) prefill_ok = 0;                       /* helpers cannot write this CU's LDS */
             if (n2 > 0 && !fork3) {
-                const int e = slip_mul_rows_out(P.Llimbs, P.xrow, P.xd, P.xcap, M, Md, wl2, wave, nw, n2, sb, prefill_ok ? ctab : (uint32_t *) 0, ckeys);
+                const int e = slip_mul_rows_any(P, k, Md, wl2, wave, nw, n2, sb);     /* inline: once per column */
                 if (e && lane == 0) sv[SV_ERR] = 1;
             }
             slip_drain_end(P, lds, forked, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
@@ -1420,7 +1409,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     {
         int mx = 0;
         for (int t = tid; t < npat; t += T) {
-            if (prefill_ok && t >= nU && diroff[t] != 0xFFFFFFFFu) {     /* entered by the multiplying wave */
+            if (prefill_ok && t >= nU && diroff[t] == 0x7FFFFFFFu) {     /* entered by the lane that produced the value */
                 const int l = slip_abs((int32_t) tab[4 * t + 1]);
                 if (l > mx) mx = l;
                 continue;
@@ -1453,7 +1442,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         auto key_of = [&](int t) -> uint64_t {
             const int32_t xl = ent_len(nU + t);
             if (xl == 0) return ~0ull;
-            const bool pre = prefill_ok && diroff[nU + t] != 0xFFFFFFFFu;
+            const bool pre = prefill_ok && diroff[nU + t] == 0x7FFFFFFFu;
             const uint64_t top = pre ? ((uint64_t) ckeys[2 * (nU + t)] | ((uint64_t) ckeys[2 * (nU + t) + 1] << 32))
                                      : slip_top64(ent_digits(nU + t), slip_abs(xl));
             const uint64_t v = ((uint64_t) ent_bits(nU + t) << 40) | (top >> 24);
@@ -1645,11 +1634,30 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     const uint64_t totLexact = baseL + dirL;
     if (Unz + nUe > P.Ucap_nz || Unl + (int64_t) totU > P.Ucap_nl) return SLIPDEV_GROW_U;
     if (Lnz + nL > P.Lcap_nz || Lnl + (int64_t) totL > P.Lcap_nl) return SLIPDEV_GROW_L;
+#ifdef SLIP_PROFILING
+    slip_vm_drain();                 /* diagnostic build: charge the wait for this phase's own stores to this phase */
+#endif
     slip_block_sync();
     SLIP_STAMP(5);
     /* limbs: one wave per entry, coalesced; x rows are stored padded to whole limbs and nobody reads
      * the slabs before the barrier below.  Rows that already live in the L slab are not copied. */
-    for (int e = wave; e < nE; e += nw) {
+#ifdef SLIP_PROFILING
+    for (int rep_ = 0; rep_ < 2; rep_++) {       /* diagnostic build: the (idempotent) copy twice, second pass on warm caches */
+    if (rep_ == 1) SLIP_STAMP(14);
+#endif
+    /* the lanes of a wave look at its entries side by side and only the entries that really need a copy (U entries,
+     * L rows that are not already in the slab) are then walked one after the other */
+    for (int base = wave; base < nE; base += nw * SLIP_WAVE) {
+    uint64_t todo_e;
+    {
+        const int el = base + nw * lane;
+        int need = 0;
+        if (el < nE) need = (use_tab && el >= nUe) ? !(tab[4 * (el - 1) + 3] >> 31) : 1;
+        todo_e = slip_ballot(need);
+    }
+    while (todo_e) {
+        const int e = base + nw * slip_ctz64(todo_e);
+        todo_e &= todo_e - 1;
         const int isU = e < nUe;
         const dig_t *srcx; dig_t *dst; int32_t xl;
         if (use_tab && isU) {
@@ -1683,7 +1691,11 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         const int lw = (slip_abs(xl) + 1) & ~1;
         for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = srcx[c];
     }
-    SLIP_STAMP(14);                                       /* wave 0 through its share of the copy */
+    }
+#ifdef SLIP_PROFILING
+    }
+    SLIP_STAMP(15);                                       /* second pass of wave 0's share */
+#endif
     slip_block_sync();
     SLIP_STAMP(6);
     /* pivot bookkeeping (slip_get_pivot.c:164-182); wave 0 */

@@ -27,6 +27,7 @@
 static inline int slip_tid(void)      { return emu::tid(); }
 static inline int slip_nthreads(void) { return emu::nthreads(); }
 static inline int slip_block(void)    { return emu::block(); }
+static inline int slip_uniform_i32(int v) { return v; }
 static inline int slip_nblocks(void)  { return emu::nblocks(); }
 /* macros, so that the divergence check sees the CALL SITE's line */
 #define slip_block_sync()      emu::block_sync(__LINE__)
@@ -85,6 +86,7 @@ static inline int slip_popc64(uint64_t v) { return __builtin_popcountll(v); }
 SLIP_DEV int slip_tid(void)      { return (int) threadIdx.x; }
 SLIP_DEV int slip_nthreads(void) { return (int) blockDim.x; }
 SLIP_DEV int slip_block(void)    { return (int) blockIdx.x; }
+SLIP_DEV int slip_uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }   /* v is the same in every lane */
 SLIP_DEV int slip_nblocks(void)  { return (int) gridDim.x; }
 SLIP_DEV void slip_block_sync(void) { __syncthreads(); }
 /* orders this wave's LDS/global writes before its lanes' later cross-lane reads */
@@ -168,7 +170,9 @@ SLIP_DEV int slip_popc64(uint64_t v) { return __popcll(v); }
 #endif
 
 SLIP_DEV int slip_lane(void)   { return slip_tid() & (SLIP_WAVE - 1); }
-SLIP_DEV int slip_wave(void)   { return slip_tid() >> 6; }
+/* wave-uniform by construction: handing it to the compiler as a scalar turns the wave-strided loops and their
+ * branches into SALU code instead of exec-masked VALU code */
+SLIP_DEV int slip_wave(void)   { return slip_uniform_i32(slip_tid() >> 6); }
 SLIP_DEV int slip_nwaves(void) { return slip_nthreads() >> 6; }
 
 /* value of lane (lane-d), own value for lanes < d */

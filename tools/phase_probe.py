@@ -16,11 +16,11 @@ for name in sys.argv[1:]:
     i = f.info()
     out = (C.c_ulonglong * 20)()
     f.lib.slip_hip_factor_phase_cycles(f.h, out)
-    tot = (sum(out[:8]) + sum(out[8:11]) + sum(out[12:15])) or 1
+    tot = (sum(out[:8]) + sum(out[8:11]) + sum(out[12:16])) or 1
     print(name, "K", i["K"], "kernel_ms %.2f" % i["kernel_ms"], "cycles/col %.0f" % (tot / max(i["K"], 1)),
           " ".join(f"{n}={100.0 * out[j] / tot:.1f}%" for j, n in enumerate(names)),
           "| Lhist parts (cycles/col): stage=%d lanes=%d waves=%d wave_items/col=%.1f" % (
               out[8] / max(i["K"], 1), out[9] / max(i["K"], 1), out[10] / max(i["K"], 1), out[11] / max(i["K"], 1)),
-          "| pivot parts: table=%d keys=%d (rest in pivot) | copy loop=%d (barrier in copy)" % (
-              out[12] / max(i["K"], 1), out[13] / max(i["K"], 1), out[14] / max(i["K"], 1)))
+          "| pivot parts: table=%d keys=%d (rest in pivot) | copy loop: first pass=%d second pass=%d (barrier in copy)" % (
+              out[12] / max(i["K"], 1), out[13] / max(i["K"], 1), out[14] / max(i["K"], 1), out[15] / max(i["K"], 1)))
     f.close()
