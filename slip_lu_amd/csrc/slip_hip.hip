@@ -74,7 +74,12 @@ __global__ void __launch_bounds__(64 * SLIP_MAX_WAVES)
 slip_factor_kernel(SlipParams P, SlipState *st)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t slip_lds[];
-    slip_factor_columns<FAST>(P, st, slip_lds);      /* block 0: column loop; blocks >= 1: helpers */
+    /* the parameters live in LDS for the whole launch: ~75 dwords held in SGPRs across the column loop made the
+     * compiler spill scalars into VGPR lanes all over the lane-level phases */
+    __shared__ SlipParams sP;
+    if (threadIdx.x == 0) sP = P;
+    __syncthreads();
+    slip_factor_columns<FAST>(sP, st, slip_lds);     /* block 0: column loop; blocks >= 1: helpers */
 }
 
 template <bool FAST>

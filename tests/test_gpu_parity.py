@@ -169,3 +169,15 @@ def test_gpu_subtree_farm_law():
         return r
     T.check_farm(gpu_factor)
     T.check_farm(gpu_factor, sizes=(40, 25, 60), seed=5)
+
+
+@pytest.mark.parametrize("name,kw", [("prob159", dict(fork_min=1, helpers=7)), ("gen_n300", dict(fork_min=1, helpers=0)),
+                                     ("rl5934", dict(fork_min=2, helpers=63)), ("C4_n100k_c64", dict(fork_min=1))])
+def test_gpu_every_batch_kind_through_the_handoff(name, kw):
+    """fork_min this low sends every queue -- IPGE updates (kind 1), history rows (2) and the one-limb rows multiplied
+    straight into the L slab (kind 3, threshold 10*fork_min) -- through the publish/acquire hand-off (or, without
+    helpers, through the published-batch path on the master); results must not depend on who did the work."""
+    entry, fix = load_case(name)
+    res = _run(entry, fix, **kw)
+    assert res["status"] == entry["status"]
+    check_against_golden(entry, fix, res)
