@@ -153,6 +153,14 @@ SLIP_DEV uint64_t slip_shfl_up_u64(uint64_t v, int d)
     return slip_shfl_u64(v, s < 0 ? l : s);
 }
 
+/* maximum over the lanes of a wave (all lanes call) */
+SLIP_DEV int slip_wave_max_i32(int v)
+{
+    const int lane = slip_lane();
+    for (int d = 32; d >= 1; d >>= 1) { const int o = (int) slip_shfl_u32((uint32_t) v, lane ^ d); if (o > v) v = o; }
+    return v;
+}
+
 /* exclusive prefix sums of two values over the workgroup's threads; totals returned */
 SLIP_DEV void slip_block_scan2(uint64_t a, uint64_t b, uint64_t *tmp, uint64_t *ea, uint64_t *eb,
                                uint64_t *ta, uint64_t *tb)
@@ -872,13 +880,13 @@ SLIP_DEV int slip_drain_begin(const SlipParams &P, uint32_t *lds, int kind, int 
     if (kind == 1 || kind == 2)
         for (int t0 = 0; t0 < nq; t0 += T) {
             const int t = t0 + tid;
-            int has = 0, h = 0, Wh = 0;
+            int has = 0, h = 0, Wh = 0, wantD = 0, wantR = 0;
             if (t < nq && kind == 1) {
                 const int i = (int) wl[2 * t + 1];
                 const SlipIpgePlan pl = slip_ipge_plan(P, i, j, jn, m0 + (int64_t) wl[2 * t], k);
                 if (pl.W2 <= P.wcap) {                                     /* else the item itself reports the short buffer */
-                    if (pl.has_d) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_D], pl.W);
-                    if (pl.fk >= 0) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_R], pl.Wf);
+                    if (pl.has_d) wantD = pl.W;
+                    if (pl.fk >= 0) wantR = pl.Wf;
                     if (pl.hdiv) { h = P.xrow[i].h; Wh = pl.W1; has = *(volatile int32_t *) &P.piv[h].invlen < Wh; }
                 }
             } else if (t < nq) {
@@ -889,6 +897,9 @@ SLIP_DEV int slip_drain_begin(const SlipParams &P, uint32_t *lds, int kind, int 
                     has = *(volatile int32_t *) &P.piv[h].invlen < Wh;
                 }
             }
+            wantD = slip_wave_max_i32(wantD); wantR = slip_wave_max_i32(wantR);    /* one LDS atomic per wave, not per item */
+            if (lane == 0 && wantD > 0) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_D], wantD);
+            if (lane == 0 && wantR > 0) slip_atomic_max_i32((int32_t *) &sv[SV_PLAN_R], wantR);
             slip_plan_push(sv, todo, has, h, Wh);
         }
     slip_block_sync();
@@ -1110,7 +1121,10 @@ SLIP_DEV void slip_sweep(const SlipParams &P, const int k, uint32_t *lds, uint32
                     slip_block_sync();
                 }
                 const int64_t me = mb + SLIP_WORK_CAP < m1 ? mb + SLIP_WORK_CAP : m1;
-                for (int64_t m = mb + tid; m < me; m += T) {
+                for (int64_t mm = mb; mm < me; mm += T) {
+                    const int64_t m = mm + tid;
+                    int queue = 0, qi = 0;                   /* this lane's update goes to the wave-item queue */
+                    if (m < me) do {
                     const int i = P.Li[m];
                     const SlipEnt le = P.Le[m];
                     const int inew = P.pinv[i];
@@ -1120,9 +1134,9 @@ SLIP_DEV void slip_sweep(const SlipParams &P, const int k, uint32_t *lds, uint32
                     SlipRow xi;
                     if (!(old & bit)) { xi.len = 0; xi.h = -1; xi.bits = 0; xi.pad = 0; P.xrow[i] = xi; }
                     else xi = P.xrow[i];
-                    if (!src_nz) continue;
+                    if (!src_nz) break;
                     c_str++; c_read += 4 + 8ull * slip_limbs(le.len);
-                    if (inew <= jn || le.len == 0) continue;
+                    if (inew <= jn || le.len == 0) break;
                     c_upd++;
                     /* ---- one-limb operands: finish the update in this lane ---- */
                     int done = 0;
@@ -1153,9 +1167,16 @@ SLIP_DEV void slip_sweep(const SlipParams &P, const int k, uint32_t *lds, uint32
                             done = 1;
                         }
                     }
-                    if (!done) {
-                        const int at = slip_atomic_add_i32((int32_t *) wcnt, 1);
-                        wl[2 * at] = (uint32_t)(m - m0); wl[2 * at + 1] = (uint32_t) i;
+                    if (!done) { queue = 1; qi = i; }
+                    } while (0);
+                    /* queue slots per wave: one LDS atomic per wave instead of one per update on the same counter */
+                    const uint64_t qm = slip_ballot(queue);
+                    int qbase = 0;
+                    if (lane == 0 && qm) qbase = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(qm));
+                    qbase = (int) slip_shfl_u32((uint32_t) qbase, 0);
+                    if (queue) {
+                        const int at = qbase + slip_popc64(qm & ((1ull << lane) - 1ull));
+                        wl[2 * at] = (uint32_t)(m - m0); wl[2 * at + 1] = (uint32_t) qi;
                     }
                 }
             }
@@ -1303,14 +1324,22 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         for (int t0 = 0; t0 < nL; t0 += SLIP_WORK_CAP) {
             const int te = t0 + SLIP_WORK_CAP < nL ? t0 + SLIP_WORK_CAP : nL;
             const unsigned long long chunk_base = (unsigned long long) sv64[SV_LALLOC / 2];
-            for (int t = t0 + tid; t < te; t += T) {
-                const int r = row_at(nU + t);
-                const SlipRow xr = P.xrow[r];
+            for (int tb = t0; tb < te; tb += T) {
+                /* every lane classifies its row; list slots are then handed out per WAVE (one LDS atomic per wave and list
+                 * instead of one per row on the same counter) */
+                const int t = tb + tid;
+                int cls = 0, r = 0;                          /* 1: one limb times the long pivot, 2: wave item (division) */
+                SlipRow xr; xr.len = 0; xr.h = 0; xr.bits = 0; xr.pad = 0;
+                uint64_t xv = 0;
+                if (t < te) {
+                r = row_at(nU + t);
+                xr = P.xrow[r];
                 if (npat <= SLIP_PAT_CAP) diroff[nU + t] = 0xFFFFFFFFu;
-                if (xr.len == 0 || xr.h >= k - 1) continue;
+                }
+                if (t < te && !(xr.len == 0 || xr.h >= k - 1)) {
                 int done = 0;
                 if (slip_abs(xr.len) <= 2) {
-                    const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                    xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
                     slip_u128 y = 0; int ys = 1;
                     if (slip_history_small(P, xr, xv, k - 1, xr.h, &y, &ys)) {
                         slip_store_small(P, r, y, ys, xr.h);
@@ -1326,11 +1355,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                     } else if (xr.h < 0 && lm + 2 <= P.xcap && lm + 2 <= 256) {
                         /* one limb times a long pivot, no division: wave path with the pivot in registers */
                         /* every such row gets a slot of (lm+3)/2 limbs in the L slab (the product has at most lm+2 digits) */
-                        const int at = slip_atomic_add_i32((int32_t *) wcnt2, 1);
-                        wl2[5 * at] = (uint32_t) r; wl2[5 * at + 1] = (uint32_t) xv; wl2[5 * at + 2] = (uint32_t)(xv >> 32);
-                        wl2[5 * at + 3] = ((uint32_t)(nU + t) << 3) | (xr.len < 0 ? 4u : 0u) | (uint32_t) slip_abs(xr.len);
-                        wl2[5 * at + 4] = (uint32_t)(chunk_base + (unsigned long long) at * slot);
-                        if (npat <= SLIP_PAT_CAP) diroff[nU + t] = wl2[5 * at + 4];
+                        cls = 1;
                         done = 1;
                     } else if (xr.h < 0 && lm + 2 <= P.xcap) {
                         /* beyond 256 digits: this lane walks the pivot's digits */
@@ -1352,7 +1377,25 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                         done = 1;
                     }
                 }
-                if (!done) { const int at = slip_atomic_add_i32((int32_t *) wcnt, 1); wl[at] = (uint32_t) r; }
+                if (!done) cls = 2;
+                }
+                const uint64_t m1 = slip_ballot(cls == 1), m2 = slip_ballot(cls == 2);
+                int base1 = 0, base2 = 0;
+                if (lane == 0) {
+                    if (m1) base1 = slip_atomic_add_i32((int32_t *) wcnt2, slip_popc64(m1));
+                    if (m2) base2 = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(m2));
+                }
+                base1 = (int) slip_shfl_u32((uint32_t) base1, 0); base2 = (int) slip_shfl_u32((uint32_t) base2, 0);
+                const uint64_t below = (1ull << lane) - 1ull;
+                if (cls == 1) {
+                    const int at = base1 + slip_popc64(m1 & below);
+                    wl2[5 * at] = (uint32_t) r; wl2[5 * at + 1] = (uint32_t) xv; wl2[5 * at + 2] = (uint32_t)(xv >> 32);
+                    wl2[5 * at + 3] = ((uint32_t)(nU + t) << 3) | (xr.len < 0 ? 4u : 0u) | (uint32_t) slip_abs(xr.len);
+                    wl2[5 * at + 4] = (uint32_t)(chunk_base + (unsigned long long) at * slot);
+                    if (npat <= SLIP_PAT_CAP) diroff[nU + t] = wl2[5 * at + 4];
+                } else if (cls == 2) {
+                    wl[base2 + slip_popc64(m2 & below)] = (uint32_t) r;
+                }
             }
             slip_block_sync();
             SLIP_STAMP(9);
@@ -1423,7 +1466,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                 tab[4 * t + 3] = xr.pad ? (0x80000000u | diroff[t]) : 0u;      /* use_tab implies the pattern is in LDS */
             }
         }
-        if (mx > 0) slip_atomic_max_i32((int32_t *) &sv[SV_MAXDIG], mx);
+        mx = slip_wave_max_i32(mx);
+        if (mx > 0 && lane == 0) slip_atomic_max_i32((int32_t *) &sv[SV_MAXDIG], mx);
         slip_block_sync();
     }
     const int maxdig = sv[SV_MAXDIG];
