@@ -130,10 +130,10 @@ def main():
     assert info["b_read"] == idx["counters"]["B_read"] and info["b_write"] == idx["counters"]["B_write"]
 
     # HBM traffic per launch from the PMC passes of this round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    # separate runs; profiles/r01/v7_pmc_summary.json): counters cannot be read from inside this process
+    # separate runs; profiles/r01/v8_pmc_summary.json): counters cannot be read from inside this process
     traffic = None
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01", "v7_pmc_summary.json")))["hbm_bytes_per_launch"]
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01", "v8_pmc_summary.json")))["hbm_bytes_per_launch"]
     except Exception:
         pass
 
