@@ -685,8 +685,8 @@ template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const Sl
             const int sh = len ? slip_clz32(d1) : 0;
             if (sh) top = (top << sh) | (uint64_t)(d3 >> (32 - sh));
             const int pidx = (int)(rec3 >> 3);
-            ctab[4 * pidx] = (uint32_t) r; ctab[4 * pidx + 1] = (uint32_t) slen; ctab[4 * pidx + 2] = (uint32_t) bits;
-            ctab[4 * pidx + 3] = 0x80000000u | slot_off;
+            ctab[0 * SLIP_TAB_CAP + pidx] = (uint32_t) r; ctab[1 * SLIP_TAB_CAP + pidx] = (uint32_t) slen; ctab[2 * SLIP_TAB_CAP + pidx] = (uint32_t) bits;
+            ctab[3 * SLIP_TAB_CAP + pidx] = 0x80000000u | slot_off;
             ckeys[2 * pidx] = (uint32_t) top; ckeys[2 * pidx + 1] = (uint32_t)(top >> 32);
         }
     }
@@ -1345,8 +1345,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                         slip_store_small(P, r, y, ys, xr.h);
                         if (npat <= SLIP_PAT_CAP) {          /* the lane has the value: table entry and pivot key from registers */
                             const int yb = slip_bits128(y), yl = (yb + 31) >> 5, pidx = nU + t;
-                            ctab[4 * pidx] = (uint32_t) r; ctab[4 * pidx + 1] = (uint32_t)(ys < 0 ? -yl : yl);
-                            ctab[4 * pidx + 2] = (uint32_t) yb; ctab[4 * pidx + 3] = 0u;
+                            ctab[0 * SLIP_TAB_CAP + pidx] = (uint32_t) r; ctab[1 * SLIP_TAB_CAP + pidx] = (uint32_t)(ys < 0 ? -yl : yl);
+                            ctab[2 * SLIP_TAB_CAP + pidx] = (uint32_t) yb; ctab[3 * SLIP_TAB_CAP + pidx] = 0u;
                             const uint64_t top = yb ? (uint64_t)((y << (128 - yb)) >> 64) : 0ull;
                             ckeys[2 * pidx] = (uint32_t) top; ckeys[2 * pidx + 1] = (uint32_t)(top >> 32);
                             diroff[pidx] = 0x7FFFFFFFu;      /* entered, value in its x row */
@@ -1431,29 +1431,30 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     SLIP_STAMP(3);
 
     /* ---- phase 5: column-window cap, then the pivot search ---- */
-    /* column table in LDS (row, signed length, bit length per pattern entry): read once, used by
+    /* column table in LDS (four arrays of SLIP_TAB_CAP words: row, signed length, bit length, flag/offset per pattern
+     * entry -- struct-of-arrays so that consecutive lanes hit consecutive banks): read once, used by
      * the cap test, the pivot search, the offsets and the copy below */
     uint32_t *tab = lds + SLIP_LDS_TAB;
     const bool use_tab = npat <= SLIP_TAB_CAP;
     const int64_t Lnl0 = sv64[SV_LNL / 2];              /* L slab cursor at the start of this column */
-    auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[4 * t] : row_at(t); };
-    auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[4 * t + 1] : P.xrow[row_at(t)].len; };
-    auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[4 * t + 2] : P.xrow[row_at(t)].bits; };
+    auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[0 * SLIP_TAB_CAP + t] : row_at(t); };
+    auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[1 * SLIP_TAB_CAP + t] : P.xrow[row_at(t)].len; };
+    auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[2 * SLIP_TAB_CAP + t] : P.xrow[row_at(t)].bits; };
     /* where the digits of a row are: its x row, or (rows multiplied straight into L) the slab */
     auto row_digits = [&](int r) -> const dig_t * {
         const dig_t *X = P.xd + (int64_t) r * P.xcap;
         return P.xrow[r].pad ? (const dig_t *)(P.Llimbs + *(const int64_t *) X) : X;
     };
     auto ent_digits = [&](int t) -> const dig_t * {
-        if (use_tab) return (tab[4 * t + 3] >> 31) ? (const dig_t *)(P.Llimbs + Lnl0 + (int64_t)(tab[4 * t + 3] & 0x7FFFFFFFu))
-                                                  : P.xd + (int64_t) tab[4 * t] * P.xcap;
+        if (use_tab) return (tab[3 * SLIP_TAB_CAP + t] >> 31) ? (const dig_t *)(P.Llimbs + Lnl0 + (int64_t)(tab[3 * SLIP_TAB_CAP + t] & 0x7FFFFFFFu))
+                                                  : P.xd + (int64_t) tab[0 * SLIP_TAB_CAP + t] * P.xcap;
         return row_digits(row_at(t));
     };
     {
         int mx = 0;
         for (int t = tid; t < npat; t += T) {
             if (prefill_ok && t >= nU && diroff[t] == 0x7FFFFFFFu) {     /* entered by the lane that produced the value */
-                const int l = slip_abs((int32_t) tab[4 * t + 1]);
+                const int l = slip_abs((int32_t) tab[1 * SLIP_TAB_CAP + t]);
                 if (l > mx) mx = l;
                 continue;
             }
@@ -1462,8 +1463,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             const int l = slip_abs(xr.len);
             if (l > mx) mx = l;
             if (use_tab) {
-                tab[4 * t] = (uint32_t) r; tab[4 * t + 1] = (uint32_t) xr.len; tab[4 * t + 2] = (uint32_t) xr.bits;
-                tab[4 * t + 3] = xr.pad ? (0x80000000u | diroff[t]) : 0u;      /* use_tab implies the pattern is in LDS */
+                tab[0 * SLIP_TAB_CAP + t] = (uint32_t) r; tab[1 * SLIP_TAB_CAP + t] = (uint32_t) xr.len; tab[2 * SLIP_TAB_CAP + t] = (uint32_t) xr.bits;
+                tab[3 * SLIP_TAB_CAP + t] = xr.pad ? (0x80000000u | diroff[t]) : 0u;      /* use_tab implies the pattern is in LDS */
             }
         }
         mx = slip_wave_max_i32(mx);
@@ -1630,10 +1631,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     uint32_t pvd[4] = {0u, 0u, 0u, 0u};
     int pv_ok = 0;
     if (use_tab && wave == nU % nw) {
-        const int lwp = (slip_abs((int32_t) tab[4 * pividx + 1]) + 1) & ~1;
+        const int lwp = (slip_abs((int32_t) tab[1 * SLIP_TAB_CAP + pividx]) + 1) & ~1;
         if (lwp <= 4 * SLIP_WAVE) {
-            const dig_t *src = (tab[4 * pividx + 3] >> 31) ? (const dig_t *)(P.Llimbs + Lnl + (int64_t)(tab[4 * pividx + 3] & 0x7FFFFFFFu))
-                                                          : P.xd + (int64_t) tab[4 * pividx] * P.xcap;
+            const dig_t *src = (tab[3 * SLIP_TAB_CAP + pividx] >> 31) ? (const dig_t *)(P.Llimbs + Lnl + (int64_t)(tab[3 * SLIP_TAB_CAP + pividx] & 0x7FFFFFFFu))
+                                                          : P.xd + (int64_t) tab[0 * SLIP_TAB_CAP + pividx] * P.xcap;
 #pragma unroll
             for (int qd = 0; qd < 4; qd++) { const int c = SLIP_WAVE * qd + lane; pvd[qd] = c < lwp ? src[c] : 0u; }
             pv_ok = 1;
@@ -1651,7 +1652,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             r = ent_row(pt); xl = ent_len(pt); xb = ent_bits(pt);
             if (e < nUe) lu = (uint64_t) slip_limbs(xl);
             else {
-                if (use_tab) { direct = (int)(tab[4 * pt + 3] >> 31); doff = Lnl + (int64_t)(tab[4 * pt + 3] & 0x7FFFFFFFu); }
+                if (use_tab) { direct = (int)(tab[3 * SLIP_TAB_CAP + pt] >> 31); doff = Lnl + (int64_t)(tab[3 * SLIP_TAB_CAP + pt] & 0x7FFFFFFFu); }
                 else if (P.xrow[r].pad) { direct = 1; doff = *(const int64_t *)(P.xd + (int64_t) r * P.xcap); }
                 if (!direct) ll = (uint64_t) slip_limbs(xl);
                 else lu = (uint64_t) slip_limbs(xl) << 32;             /* summed in the high half of the U channel */
@@ -1669,7 +1670,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
                 const int64_t at = Lnz + (e - nUe);
                 const int64_t off = direct ? doff : Lnl + (int64_t)(lalloc + baseL + el);
                 if (at < P.Lcap_nz) { P.Li[at] = r; SlipEnt en; en.len = xl; en.bits = xb; en.off = off; P.Le[at] = en; }
-                if (use_tab && !direct) tab[4 * pt + 3] = (uint32_t)(off - Lnl);     /* copy destination, flag bit clear */
+                if (use_tab && !direct) tab[3 * SLIP_TAB_CAP + pt] = (uint32_t)(off - Lnl);     /* copy destination, flag bit clear */
             }
         }
         baseU += tu & 0xFFFFFFFFull; dirL += tu >> 32; baseL += tl;
@@ -1696,7 +1697,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
     {
         const int el = base + nw * lane;
         int need = 0;
-        if (el < nE) need = (use_tab && el >= nUe) ? !(tab[4 * (el - 1) + 3] >> 31) : 1;
+        if (el < nE) need = (use_tab && el >= nUe) ? !(tab[3 * SLIP_TAB_CAP + (el - 1)] >> 31) : 1;
         todo_e = slip_ballot(need);
     }
     while (todo_e) {
@@ -1707,9 +1708,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
         if (use_tab && isU) {
             /* U(:,k): pivotal rows live in x; the pivot (last) may have been multiplied straight into the L slab */
             const int pt = e < nU ? e : pividx;
-            xl = (int32_t) tab[4 * pt + 1];
-            srcx = (tab[4 * pt + 3] >> 31) ? (const dig_t *)(P.Llimbs + Lnl + (int64_t)(tab[4 * pt + 3] & 0x7FFFFFFFu))
-                                           : P.xd + (int64_t) tab[4 * pt] * P.xcap;
+            xl = (int32_t) tab[1 * SLIP_TAB_CAP + pt];
+            srcx = (tab[3 * SLIP_TAB_CAP + pt] >> 31) ? (const dig_t *)(P.Llimbs + Lnl + (int64_t)(tab[3 * SLIP_TAB_CAP + pt] & 0x7FFFFFFFu))
+                                           : P.xd + (int64_t) tab[0 * SLIP_TAB_CAP + pt] * P.xcap;
             dst = (dig_t *)(P.Ulimbs + Unl + (int64_t) work[e]);
             if (e == nU && pv_ok) {
                 const int lwp = (slip_abs(xl) + 1) & ~1;
@@ -1719,10 +1720,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, uin
             }
         } else if (use_tab) {
             const int pt = e - 1;
-            if (tab[4 * pt + 3] >> 31) continue;                 /* multiplied straight into the slab */
-            xl = (int32_t) tab[4 * pt + 1];
-            srcx = P.xd + (int64_t) tab[4 * pt] * P.xcap;
-            dst = (dig_t *)(P.Llimbs + Lnl + (int64_t) tab[4 * pt + 3]);
+            if (tab[3 * SLIP_TAB_CAP + pt] >> 31) continue;                 /* multiplied straight into the slab */
+            xl = (int32_t) tab[1 * SLIP_TAB_CAP + pt];
+            srcx = P.xd + (int64_t) tab[0 * SLIP_TAB_CAP + pt] * P.xcap;
+            dst = (dig_t *)(P.Llimbs + Lnl + (int64_t) tab[3 * SLIP_TAB_CAP + pt]);
         } else {
             const int64_t at = isU ? Unz + e : Lnz + (e - nUe);
             const int r = isU ? P.Ui[at] : P.Li[at];
