@@ -1902,16 +1902,26 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
         slip_block_sync();
         for (int t0 = 0; t0 < npat; t0 += SLIP_WORK_CAP) {
             const int te = t0 + SLIP_WORK_CAP < npat ? t0 + SLIP_WORK_CAP : npat;
-            for (int t = t0 + tid; t < te; t += T) {
-                const int r = P.row_perm[pat_at(t)];
-                const SlipRow xr = P.xrow[r];
-                if (xr.len == 0) continue;
-                slip_u128 y = 0; int ys = 1; int done = 0;
-                if (slip_abs(xr.len) <= 2) {
-                    const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
-                    if (slip_history_small(P, xr, xv, n - 1, -1, &y, &ys)) { slip_store_small(P, r, y, ys, xr.h); done = 1; }
-                }
-                if (!done) { const int at = slip_atomic_add_i32((int32_t *) wcnt, 1); work[at] = (uint32_t) r; }
+            for (int tb = t0; tb < te; tb += T) {
+                const int t = tb + tid;
+                int queue = 0, r = 0;
+                if (t < te) do {
+                    r = P.row_perm[pat_at(t)];
+                    const SlipRow xr = P.xrow[r];
+                    if (xr.len == 0) break;
+                    slip_u128 y = 0; int ys = 1; int done = 0;
+                    if (slip_abs(xr.len) <= 2) {
+                        const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                        if (slip_history_small(P, xr, xv, n - 1, -1, &y, &ys)) { slip_store_small(P, r, y, ys, xr.h); done = 1; }
+                    }
+                    if (!done) queue = 1;
+                } while (0);
+                /* queue slots per wave (one LDS atomic per wave, not per row on the same counter) */
+                const uint64_t qm = slip_ballot(queue);
+                int qbase = 0;
+                if (lane == 0 && qm) qbase = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(qm));
+                qbase = (int) slip_shfl_u32((uint32_t) qbase, 0);
+                if (queue) work[qbase + slip_popc64(qm & ((1ull << lane) - 1ull))] = (uint32_t) r;
             }
             slip_block_sync();
             slip_drain(P, lds, 4, 0, 0, n, 0, *wcnt, work, b0, b1, b2);
@@ -1950,7 +1960,10 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
             const int64_t m0 = P.Up[jp], m1 = P.Up[jp + 1] - 1;   /* the pivot is the last entry */
             for (int64_t mb = m0; mb < m1; mb += SLIP_WORK_CAP) {
                 const int64_t me = mb + SLIP_WORK_CAP < m1 ? mb + SLIP_WORK_CAP : m1;
-                for (int64_t m = mb + tid; m < me; m += T) {
+                for (int64_t mm = mb; mm < me; mm += T) {
+                    const int64_t m = mm + tid;
+                    int queue = 0, qi = 0;
+                    if (m < me) do {
                     const int i = P.Ui[m];
                     const SlipEnt ue = P.Ue[m];
                     const int pos = P.pinv[i];
@@ -1959,7 +1972,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
                     SlipRow xi;
                     if (!(old & bit)) { xi.len = 0; xi.h = -1; xi.bits = 0; xi.pad = 0; P.xrow[i] = xi; }
                     else xi = P.xrow[i];
-                    if (ue.len == 0) continue;
+                    if (ue.len == 0) break;
                     int done = 0;
                     if (slip_abs(ue.len) <= 2 && slip_abs(xj.len) <= 2 && slip_abs(xi.len) <= 2) {
                         const int bt = (xi.bits > ue.bits + xj.bits ? xi.bits : ue.bits + xj.bits) + 1;
@@ -1977,9 +1990,15 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
                             done = 1;
                         }
                     }
-                    if (!done) {
-                        const int at = slip_atomic_add_i32((int32_t *) wcnt, 1);
-                        work[2 * at] = (uint32_t)(m - m0); work[2 * at + 1] = (uint32_t) i;
+                    if (!done) { queue = 1; qi = i; }
+                    } while (0);
+                    const uint64_t qm = slip_ballot(queue);          /* queue slots per wave */
+                    int qbase = 0;
+                    if (lane == 0 && qm) qbase = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(qm));
+                    qbase = (int) slip_shfl_u32((uint32_t) qbase, 0);
+                    if (queue) {
+                        const int at = qbase + slip_popc64(qm & ((1ull << lane) - 1ull));
+                        work[2 * at] = (uint32_t)(m - m0); work[2 * at + 1] = (uint32_t) qi;
                     }
                 }
                 slip_block_sync();
