@@ -184,6 +184,25 @@ SLIP_DEV void slip_block_scan2(uint64_t a, uint64_t b, uint64_t *tmp, uint64_t *
 }
 
 /* workgroup minimum of a 64-bit key (all threads get it) */
+/* the same for two counts whose totals stay below 2^32: both travel in one 64-bit word (half the shuffles) */
+SLIP_DEV void slip_block_scan2_small(uint32_t a, uint32_t b, uint64_t *tmp, uint32_t *ea, uint32_t *eb, uint32_t *ta, uint32_t *tb)
+{
+    const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    const uint64_t v = (uint64_t) a | ((uint64_t) b << 32);
+    uint64_t iv = v;
+    for (int d = 1; d < SLIP_WAVE; d <<= 1) {
+        const uint64_t x = slip_shfl_up_u64(iv, d);
+        if (lane >= d) iv += x;
+    }
+    if (lane == SLIP_WAVE - 1) tmp[wave] = iv;
+    slip_block_sync();
+    uint64_t before = 0, total = 0;
+    for (int w = 0; w < nw; w++) { const uint64_t x = tmp[w]; if (w < wave) before += x; total += x; }
+    slip_block_sync();
+    const uint64_t ex = before + iv - v;
+    *ea = (uint32_t) ex; *eb = (uint32_t)(ex >> 32); *ta = (uint32_t) total; *tb = (uint32_t)(total >> 32);
+}
+
 SLIP_DEV uint64_t slip_block_min_u64(uint64_t v, uint64_t *tmp)
 {
     const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
@@ -1204,8 +1223,8 @@ SLIP_DEV void slip_pattern(const SlipParams &P, uint32_t *lds, const uint32_t *b
         else below = word & ((1u << (k - w * 32)) - 1u);
         cntA += (uint64_t) slip_popc32(word); cntU += (uint64_t) slip_popc32(below);
     }
-    uint64_t exA, exU, totA, totU_;
-    slip_block_scan2(cntA, cntU, scan_tmp, &exA, &exU, &totA, &totU_);
+    uint32_t exA, exU, totA, totU_;              /* at most n < 2^31 set bits */
+    slip_block_scan2_small((uint32_t) cntA, (uint32_t) cntU, scan_tmp, &exA, &exU, &totA, &totU_);
     {
         /* short patterns never leave the CU (the readers pick the same place by npat) */
         int o = (int) exA;
