@@ -44,7 +44,7 @@ typedef struct slip_hip_options {
     double  tol;          /* SLIP_options.tol; default 1.0                             */
     int32_t limb_cap;     /* > 0: column-window mode -- stop BEFORE the first column   */
                           /*      that holds a value of more than limb_cap limbs       */
-    int32_t waves;        /* waves per workgroup (0 = default 16)                      */
+    int32_t waves;        /* waves per workgroup (0 = default 8)                        */
     int64_t lnz_hint;     /* initial capacity of L / U in entries (0 = 4*nnz(A)+n),    */
     int64_t unz_hint;     /*   cf. SLIP_LU_analysis.lnz/.unz; both grow on demand      */
     int32_t helpers;      /* helper workgroups (other CUs) that share multi-limb update */

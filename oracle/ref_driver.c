@@ -214,18 +214,21 @@ int main(int argc, char **argv)
         double t_acc = 0;
         int32_t k;
         for (k = 0; k < K; k++) {
+            /* timed: only what SLIP_LU_factorize.c:190-264 itself does per column (realloc check, the triangular
+             * solve, the pivot search, the L/U split); the driver's own cap scan and counter loops run untimed */
             double tk = now_s();
             L->p[k] = lnz; U->p[k] = unz;
             int32_t col = S->q[k], top, pivot;
             if (lnz + n > L->nzmax) { L->nz = lnz; if (slip_sparse_realloc(L) != SLIP_OK) DIE("realloc L"); }
             if (unz + n > U->nzmax) { U->nz = unz; if (slip_sparse_realloc(U) != SLIP_OK) DIE("realloc U"); }
             ok = slip_REF_triangular_solve(&top, L, A, k, xi, S->q, rhos, pinv, row_perm, h, x);
+            t_acc += now_s() - tk;
             if (ok != SLIP_OK) break;
             /* cap test on the finished column, BEFORE it is committed */
             if (cap > 0) {
                 int over = 0;
                 for (int32_t j = top; j < n; j++) if (zlimbs(x[xi[j]]) > cap) { over = 1; break; }
-                if (over) { t_acc += now_s() - tk; break; }
+                if (over) break;
             }
             /* counters of SURVEY.md 8(d): uses pinv BEFORE the pivot swap of column k */
             for (int32_t p = A->p[col]; p < A->p[col + 1]; p++) counters[1] += 4 + 8 * zlimbs(A->x[p]);
@@ -240,18 +243,20 @@ int main(int argc, char **argv)
                     if (pinv[L->i[m]] > jnew && mpz_sgn(L->x[m]) != 0) counters[0]++;
                 }
             }
+            tk = now_s();
             ok = slip_get_pivot(&pivot, x, pivs, n, top, xi, opt->pivot, col, k, rhos, pinv, row_perm, opt->tol);
             if (ok != SLIP_OK) break;
+            const int64_t lnz0 = lnz, unz0 = unz;
             for (int32_t j = top; j < n; j++) {
                 int32_t jnew = xi[j], loc = pinv[jnew];
                 size_t size = mpz_sizeinbase(x[jnew], 2);
-                int64_t l = zlimbs(x[jnew]);
-                if (l > counters[5]) counters[5] = l;
-                if (loc <= k) { U->i[unz] = jnew; mpz_init2(U->x[unz], size + 2); mpz_set(U->x[unz], x[jnew]); unz++; counters[2] += 4 + 8 * l; }
-                if (loc >= k) { L->i[lnz] = jnew; mpz_init2(L->x[lnz], size + 2); mpz_set(L->x[lnz], x[jnew]); lnz++; counters[2] += 4 + 8 * l; }
+                if (loc <= k) { U->i[unz] = jnew; mpz_init2(U->x[unz], size + 2); mpz_set(U->x[unz], x[jnew]); unz++; }
+                if (loc >= k) { L->i[lnz] = jnew; mpz_init2(L->x[lnz], size + 2); mpz_set(L->x[lnz], x[jnew]); lnz++; }
             }
-            counters[2] += 8 * zlimbs(rhos[k]);
             t_acc += now_s() - tk;
+            for (int64_t t = unz0; t < unz; t++) { int64_t l = zlimbs(U->x[t]); if (l > counters[5]) counters[5] = l; counters[2] += 4 + 8 * l; }
+            for (int64_t t = lnz0; t < lnz; t++) { int64_t l = zlimbs(L->x[t]); if (l > counters[5]) counters[5] = l; counters[2] += 4 + 8 * l; }
+            counters[2] += 8 * zlimbs(rhos[k]);
         }
         Kdone = k; t_factor = t_acc;
         L->nz = lnz; U->nz = unz;

@@ -172,7 +172,7 @@ template <class T> static int dev_grow(T **p, int64_t old_count, int64_t new_cou
 {
     T *q = NULL;
     if (dev_alloc(&q, new_count)) return SLIP_HIP_OUT_OF_MEMORY;
-    if (old_count > 0 && hipMemcpy(q, *p, (size_t) old_count * sizeof(T), hipMemcpyDeviceToDevice) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
+    if (old_count > 0 && hipMemcpy(q, *p, (size_t) old_count * sizeof(T), hipMemcpyDeviceToDevice) != hipSuccess) { hipFree(q); return SLIP_HIP_DEVICE_ERROR; }
     hipFree(*p);
     *p = q;
     return 0;

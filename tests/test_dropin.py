@@ -31,17 +31,42 @@ def write_triplet(path, fix, n):
                 f.write(f"{int(Ai[p]) + 1} {j + 1} {v}\n")
 
 
-@pytest.mark.parametrize("name,pivot", [("test_mat", 3), ("10teams", 3), ("prob159", 3), ("10teams", 0), ("gen_n300", 5)])
-def test_dropin_factorize_matches_reference(tmp_path, name, pivot):
+def binaries():
+    """The two builds of tests/dropin/dropin_driver.c.  They are compiled by __graft_entry__.build() in the
+    container that has the reference's headers and travel to the GPU box with the snapshot: a missing binary
+    is a broken build, not a reason to skip."""
     hip, ref = os.path.join(BUILD, "dropin_hip"), os.path.join(BUILD, "dropin_ref")
-    if not (os.path.exists(hip) and os.path.exists(ref)):
-        pytest.skip("drop-in binaries not built (need the reference's headers: make -C tests/dropin)")
+    assert os.path.exists(hip) and os.path.exists(ref), \
+        "drop-in binaries missing: run __graft_entry__.build() where /root/reference exists (make -C tests/dropin)"
+    return hip, ref
+
+
+def run_both(args):
+    hip, ref = binaries()
+    out_ref = subprocess.run([ref] + args, capture_output=True, text=True, timeout=900)
+    out_hip = subprocess.run([hip] + args, capture_output=True, text=True, timeout=900)
+    assert out_ref.returncode == 0, out_ref.stdout + out_ref.stderr
+    assert out_hip.returncode == 0, out_hip.stdout + out_hip.stderr
+    return out_hip.stdout, out_ref.stdout
+
+
+@pytest.mark.parametrize("name,pivot,nrhs", [("test_mat", 3, 1), ("10teams", 3, 1), ("prob159", 3, 1), ("10teams", 0, 1),
+                                             ("gen_n300", 5, 1), ("test_mat", 3, 2), ("gen_n300", 3, 3)])
+def test_dropin_factorize_matches_reference(tmp_path, name, pivot, nrhs):
+    """SLIP_LU_factorize + SLIP_LU_solve through libslip_lu_hip.so == the reference (L, U, rhos, pinv, x hashes),
+    the reference's own SLIP_check_solution accepts the result (and rejects a corrupted b), and the
+    reference's destructors free what the shim allocated."""
     entry, fix = load_case(name)
     trip = str(tmp_path / "A.txt")
     write_triplet(trip, fix, entry["n"])
-    out_ref = subprocess.run([ref, trip, str(pivot)], capture_output=True, text=True, timeout=600)
-    out_hip = subprocess.run([hip, trip, str(pivot)], capture_output=True, text=True, timeout=600)
-    assert out_ref.returncode == 0, out_ref.stdout + out_ref.stderr
-    assert out_hip.returncode == 0, out_hip.stdout + out_hip.stderr
-    assert out_hip.stdout.startswith("check=0 ")
-    assert out_hip.stdout == out_ref.stdout
+    got, want = run_both([trip, str(pivot), str(nrhs)])
+    assert got.startswith("check=0 check_corrupt=-4 ")
+    assert got == want
+
+
+def test_dropin_error_paths_match_reference():
+    """NULL arguments -> SLIP_INCORRECT_INPUT, a singular matrix -> SLIP_SINGULAR under three pivot schemes,
+    then SLIP_delete_sparse on whatever came back (Tcov/cov_test.c:342-345,466-472,674-678)."""
+    got, want = run_both(["--errors"])
+    assert "singular=-2" in got and "null_all factorize=-3 solve=-3" in got
+    assert got == want
