@@ -47,9 +47,9 @@ typedef struct slip_hip_options {
     int32_t waves;        /* waves per workgroup (0 = default 8)                        */
     int64_t lnz_hint;     /* initial capacity of L / U in entries (0 = 4*nnz(A)+n),    */
     int64_t unz_hint;     /*   cf. SLIP_LU_analysis.lnz/.unz; both grow on demand      */
-    int32_t helpers;      /* helper workgroups (other CUs) that share multi-limb update */
-                          /*   batches of one source: -1 = default (63), 0 = none       */
-    int32_t fork_min;     /* queue length from which a batch is farmed out (0 = default) */
+    int32_t workers;      /* column workers (workgroups of a launch; each owns a private */
+                          /*   dense vector): 0 = as many as can be resident            */
+    int32_t reserved;
 } slip_hip_options;
 
 typedef struct slip_hip_info {
@@ -63,7 +63,10 @@ typedef struct slip_hip_info {
     int64_t n_upd, b_read, b_write, n_src, l_streamed, max_limbs;
     double  kernel_ms;    /* device time of the factorisation kernels of the last run  */
     int32_t launches;     /* kernel launches of the last run (regrows relaunch)        */
-    int32_t xcap_digits;  /* current stride of the dense scatter vector, 32-bit digits */
+    int32_t xcap_digits;  /* current stride of the dense scatter vectors, 32-bit digits */
+    int64_t limb_macs;    /* sum over the IPGE updates of l(L_m)*l(x_j) + l(x_i)*l(rho_jn), 64-bit limbs */
+    int32_t workers, waves;   /* launch shape: column workers x wavefronts each          */
+    int32_t lds_bytes, pad;   /* dynamic LDS per worker                                   */
 } slip_hip_info;
 
 typedef struct slip_hip_factor slip_hip_factor;
@@ -146,9 +149,9 @@ void slip_hip_free(void *p);
 int slip_hip_wave_op_test(int32_t op, int32_t nops, int32_t la, int32_t lb, int32_t W,
                           const uint32_t *a, const uint32_t *b, uint32_t *out);
 
-/* Diagnostic builds (-DSLIP_PROFILE_PHASES) only: shader cycles thread 0 spent per phase of the
- * column loop during the last run; all zero in the product build. */
-int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out20);   /* 20 slots */
+/* Diagnostic builds (-DSLIP_PROFILE_PHASES) only: shader cycles thread 0 of every worker spent per phase of its
+ * columns during the last run (summed over the workers); all zero in the product build. */
+int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out24);   /* 24 slots */
 
 const char *slip_hip_version(void);
 

@@ -15,7 +15,7 @@ DEFAULT_SO = os.path.join(_HERE, "csrc", "libslip_hip.so")
 class Options(C.Structure):
     _fields_ = [("pivot", C.c_int32), ("tol", C.c_double), ("limb_cap", C.c_int32),
                 ("waves", C.c_int32), ("lnz_hint", C.c_int64), ("unz_hint", C.c_int64),
-                ("helpers", C.c_int32), ("fork_min", C.c_int32)]
+                ("workers", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Info(C.Structure):
@@ -23,7 +23,9 @@ class Info(C.Structure):
                 ("lnz", C.c_int64), ("unz", C.c_int64), ("l_limbs", C.c_int64), ("u_limbs", C.c_int64),
                 ("n_upd", C.c_int64), ("b_read", C.c_int64), ("b_write", C.c_int64), ("n_src", C.c_int64),
                 ("l_streamed", C.c_int64), ("max_limbs", C.c_int64),
-                ("kernel_ms", C.c_double), ("launches", C.c_int32), ("xcap_digits", C.c_int32)]
+                ("kernel_ms", C.c_double), ("launches", C.c_int32), ("xcap_digits", C.c_int32),
+                ("limb_macs", C.c_int64), ("workers", C.c_int32), ("waves", C.c_int32),
+                ("lds_bytes", C.c_int32), ("pad", C.c_int32)]
 
 
 EXPORTS = ("slip_hip_default_options", "slip_hip_device_count", "slip_hip_factor_create",

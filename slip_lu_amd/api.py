@@ -49,7 +49,7 @@ class Factorization:
     """A resident REF LU factorisation on one GPU (handle of slip_hip_factor_*)."""
 
     def __init__(self, n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, limb_cap=0, waves=0,
-                 lnz_hint=0, unz_hint=0, helpers=-1, fork_min=0, lib_path=None):
+                 lnz_hint=0, unz_hint=0, workers=0, lib_path=None):
         self.lib = _lib.load(lib_path)
         self.n = int(n)
         Ap = np.ascontiguousarray(Ap, dtype=np.int64)
@@ -59,7 +59,7 @@ class Factorization:
         if Alimbs.size == 0:
             Alimbs = np.zeros(1, dtype=np.uint64)
         q = np.ascontiguousarray(q, dtype=np.int32)
-        opt = _lib.Options(pivot, tol, limb_cap, waves, lnz_hint, unz_hint, helpers, fork_min)
+        opt = _lib.Options(pivot, tol, limb_cap, waves, lnz_hint, unz_hint, workers, 0)
         self.h = C.c_void_p()
         rc = self.lib.slip_hip_factor_create(C.byref(self.h), self.n, Ap.ctypes.data, Ai.ctypes.data,
                                              Alen.ctypes.data, Alimbs.ctypes.data, q.ctypes.data,
@@ -69,7 +69,7 @@ class Factorization:
             raise SlipError(rc, "slip_hip_factor_create")
 
     @classmethod
-    def from_factors(cls, fac, waves=0, helpers=-1, fork_min=0, lib_path=None):
+    def from_factors(cls, fac, waves=0, workers=0, lib_path=None):
         """A solve-only handle around factors in the form `download()` returns (slip_hip_factor_from_factors)."""
         self = cls.__new__(cls)
         self.lib = _lib.load(lib_path)
@@ -78,7 +78,7 @@ class Factorization:
             ("Lp", np.int64), ("Li", np.int32), ("Llen", np.int32), ("Llimbs", np.uint64),
             ("Up", np.int64), ("Ui", np.int32), ("Ulen", np.int32), ("Ulimbs", np.uint64), ("pinv", np.int32))]
         arrs = [a if a.size else np.zeros(1, a.dtype) for a in arrs]
-        opt = _lib.Options(3, 1.0, 0, waves, 0, 0, helpers, fork_min)
+        opt = _lib.Options(3, 1.0, 0, waves, 0, 0, workers, 0)
         self.h = C.c_void_p()
         rc = self.lib.slip_hip_factor_from_factors(C.byref(self.h), self.n, *[a.ctypes.data for a in arrs], C.byref(opt))
         if rc:
@@ -125,7 +125,7 @@ class Factorization:
         out["Ulimbs"] = out["Ulimbs"][:i["u_limbs"]]
         out["rholimbs"] = rho[:cap.value].copy()
         out["counters"] = np.array([i["n_upd"], i["b_read"], i["b_write"], i["n_src"], i["l_streamed"],
-                                    i["max_limbs"], K, 0], dtype=np.int64)
+                                    i["max_limbs"], K, i["limb_macs"]], dtype=np.int64)
         out["info"] = i
         return out
 
@@ -166,10 +166,10 @@ class Factorization:
 
 
 def factorize(n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, kmax=0, limb_cap=0, waves=0, check=True,
-              lib_path=None, helpers=-1, fork_min=0):
+              lib_path=None, workers=0, lnz_hint=0, unz_hint=0):
     """One-shot SLIP_LU_factorize on the GPU; returns the canonical factor dict."""
     f = Factorization(n, Ap, Ai, Alen, Alimbs, q, pivot=pivot, tol=tol, limb_cap=limb_cap, waves=waves,
-                      lib_path=lib_path, helpers=helpers, fork_min=fork_min)
+                      lib_path=lib_path, workers=workers, lnz_hint=lnz_hint, unz_hint=unz_hint)
     try:
         rc = f.run(kmax, check=check)
         out = f.download()

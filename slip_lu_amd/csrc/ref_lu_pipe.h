@@ -1,0 +1,976 @@
+/* ref_lu_pipe.h -- the left-looking REF sparse LU column loop as a PIPELINE of column workers (gfx950).
+ *
+ * Replaces, on the device, the reference's hot path
+ *   SLIP_LU/Source/SLIP_LU_factorize.c:190-264      (column loop, L/U split)
+ *   SLIP_LU/Source/slip_REF_triangular_solve.c:65-265 (reach + history/IPGE sweep)
+ *   SLIP_LU/Source/slip_reach.c, slip_dfs.c, slip_sort_xi.c (pattern, order)
+ *   SLIP_LU/Source/slip_get_pivot.c:30-183 and the smallest/largest/nonzero searches
+ * with an MI355X-first formulation rather than a translation.
+ *
+ * The reference runs the columns one after the other.  Here every workgroup of the grid is a COLUMN
+ * WORKER: it draws the next column k from a ticket counter, scatters A(:,q[k]) into its own private dense
+ * vector x and runs the ascending sweep over the pivotal part of the pattern AHEAD of the commit frontier
+ * F: a source at pivot position jn can be applied as soon as column jn is committed, because everything
+ * below the frontier is final (pivot rows, pivots, L columns) and the sweep's order is ascending anyway
+ * (slip_REF_triangular_solve.c:124-131).  Rows found non-pivotal are re-examined when the frontier moves
+ * (the row that became pivotal at position c is row_perm[c]).  Only what really depends on the previous
+ * column is serial: when F == k the worker applies source k-1 if it is in the pattern, brings the rows to
+ * level k-1, chooses the pivot, publishes it (pinv/row_perm swap, rho_k, column pointers: "stage 1",
+ * F = k+1) and then writes the bulk of L(:,k), U(:,k) ("stage 2", Lready[k]) while the next worker is
+ * already committing.  Many columns are in flight on different CUs; the chain is one short hop per column.
+ *
+ * Inside a worker the formulation of round 1 is kept:
+ *  - No DFS and no sort: the pattern is a bitmap over pivot positions (LDS) read in ascending order.
+ *  - A source's L column is streamed coalesced, one entry per LANE; one-limb updates finish in the lane
+ *    (128-bit arithmetic), the others are queued in LDS and done one per WAVEFRONT (wave_bigint_reg.h).
+ *  - Exact divisions are 2-adic with cached Newton inverses of the pivots (shared, extended on demand;
+ *    concurrent extensions write identical digits).
+ *  - Pivot search, permutation swap and the L/U append stay on the device.
+ *
+ * Memory visibility between workers (cdna_hip_programming.md, Guideline 16): everything another worker
+ * may read during the launch (pinv, row_perm, pivot records, L structure and limbs, the inverse cache,
+ * the frontier words) is written with write-through (sc1) stores, drained (vmcnt(0)) by every storing
+ * wave before ONE lane raises the flag, and read ONLY with sc1 loads (slip_ld_*), so no acquire fence is
+ * needed on the reading side.  A worker's x vector is private (plain accesses).  Nothing depends on
+ * dispatch order or residency: a workgroup that is not resident holds no ticket.
+ *
+ * Values are sign-magnitude: a signed digit count (32-bit digits) plus the magnitude; all stores are
+ * padded to whole 64-bit limbs.
+ */
+#ifndef SLIP_REF_LU_PIPE_H
+#define SLIP_REF_LU_PIPE_H
+
+#include "wave_bigint.h"
+#include "wave_bigint_reg.h"
+
+typedef unsigned __int128 slip_u128;
+
+/* status of a launch (SlipState.status) */
+enum {
+    SLIPDEV_OK = 0,          /* reached k_stop                                      */
+    SLIPDEV_SINGULAR = 1,    /* no eligible nonzero pivot in column status_k        */
+    SLIPDEV_GROW_L = 2,      /* L slab / index arrays full; column status_k not done */
+    SLIPDEV_GROW_U = 3,
+    SLIPDEV_GROW_X = 4,      /* a value needs more than xcap / wcap / invcap digits  */
+    SLIPDEV_WINDOW_END = 5,  /* column status_k holds a value above limb_cap         */
+    SLIPDEV_INTERNAL = 6     /* a wait was not answered / inconsistent state         */
+};
+
+/* state of one row of a worker's private dense scatter vector x */
+typedef struct { int32_t len, h, bits, tag; } SlipRow;            /* signed digits, history, bit length, ticket of the column it belongs to */
+/* one stored entry of L or U: where its limbs are, how long, how many bits */
+typedef struct { int64_t off; int32_t len, bits; } SlipEnt;       /* off in 64-bit limbs */
+/* one pivot rho[k] (= the pivot entry of L(:,k)) */
+typedef struct {
+    int64_t off; int32_t len, bits;          /* limbs in the L slab */
+    uint64_t lo; int32_t ctz, invlen;        /* low limb; trailing zero bits; cached inverse digits */
+    uint64_t inv64, pad;                     /* inverse of the odd part modulo 2^64 (one-limb pivots) */
+} SlipPiv;
+
+/* mutable across launches; the words other workers poll sit in 128-byte lines of their own */
+typedef struct SlipState {
+    int32_t F;  int32_t padF[31];                   /* commit frontier: columns < F have published their pivot (stage 1) */
+    int64_t stop; int64_t padS[15];                 /* (column << 8) | SLIPDEV_* of the first column that cannot commit; min wins */
+    int32_t F2; int32_t padF2[31];                  /* ready frontier: columns < F2 have published their L entries (stage 2) */
+    int32_t ticket; int32_t padT[31];               /* next column ticket (monotonic across launches)                    */
+    int32_t exited, padE[31];                       /* workers that have left the launch (the last one writes the summary) */
+    int32_t k_next, status, status_k, solve_next;
+    int64_t Lnz, Lnl, Unz, Unl;                     /* mirrors of Lp/Lo/Up/Uo at the frontier (written at kernel end)     */
+    int64_t Lnl_exact, Unl_exact;                   /* limbs actually stored                                             */
+    int64_t out_used;                               /* solve: limbs of the output slab in use                            */
+    unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig, c_macs;
+    unsigned long long prof[24];                    /* -DSLIP_PROFILE_PHASES builds only */
+} SlipState;
+
+/* immutable during a launch: passed by value, copied to LDS, private fields set per worker there */
+typedef struct SlipParams {
+    int32_t n, pivot_scheme, limb_cap, tol_mode;    /* tol_mode 0: tol <= 0          */
+    uint64_t tol_m; int32_t tol_e, k_stop;          /* tol = tol_m * 2^tol_e         */
+    const int64_t *Ap; const int32_t *Ai; const int32_t *Alen; const int64_t *Aoff;
+    const uint64_t *Alimbs; const int32_t *q;
+    int32_t *pinv, *row_perm;                       /* shared: swapped at stage 1 of every column */
+    SlipRow *xrow; uint32_t *xd;                    /* PRIVATE per worker (the kernel offsets the bases): row i's digits at xd[i*xcap] */
+    SlipPiv *piv; uint32_t *invd;                   /* shared: pivot p's inverse at invd[p*invcap] */
+    int32_t xcap, invcap, wcap, bm_words;
+    int64_t *Lp, *Lo; int32_t *Li; SlipEnt *Le; uint64_t *Llimbs; int64_t Lcap_nz, Lcap_nl;   /* Lo: limb offset of a column's first entry */
+    int64_t *Up, *Uo; int32_t *Ui; SlipEnt *Ue; uint64_t *Ulimbs; int64_t Ucap_nz, Ucap_nl;
+    int32_t *Lready;                                /* shared: column c's L entries and limbs are published (stage 2)  */
+    int32_t *pat;                                   /* PRIVATE: pattern of the column (positions, ascending) when it exceeds the LDS cap */
+    int32_t *rlist;                                 /* PRIVATE: rows of the pattern in discovery order                  */
+    uint32_t *gscratch, *gbitmap;                   /* PRIVATE: used when LDS does not hold them */
+    int32_t k0, t0;                                 /* ticket t0 + d is column k0 + d in this launch                    */
+    int32_t bitmap_in_lds, scratch_in_lds;          /* where the bitmap / wave scratch live (generic kernel)            */
+    int32_t nworkers, worker;
+    int64_t priv_rows;                              /* rows per worker of the private arrays (= n)                      */
+    int32_t *dbg;
+} SlipParams;
+
+/* arguments of the REF triangular solves (SLIP_LU_solve.c:41-86) on resident factors */
+typedef struct SlipSolveArgs {
+    int32_t nrhs, pad;
+    const int32_t *blen; const int64_t *boff; const uint64_t *blimbs;   /* dense b, entry (c,i) at c*n+i: signed digits, limb offset */
+    int32_t *olen; int64_t *ooff; uint64_t *olimbs; int64_t ocap;       /* numerators over det = rho[n-1], by pivot position        */
+    int64_t ostride;                                                     /* limbs of output slab reserved per right-hand side        */
+} SlipSolveArgs;
+
+#if defined(SLIP_PROFILE_PHASES) && !defined(SLIP_EMULATE)
+#define SLIP_STAMP(slot) do { if (tid == 0) { unsigned long long now_ = clock64(); prof_[slot] += now_ - t_prev_; t_prev_ = now_; } } while (0)
+#define SLIP_PROFILING 1
+#define SLIP_STAMP_INIT() unsigned long long t_prev_ = clock64(); unsigned long long prof_[24] = {0}
+#define SLIP_STAMP_FLUSH(st) do { if (tid == 0) for (int s_ = 0; s_ < 24; s_++) if (prof_[s_]) slip_agent_add_u64(&(st)->prof[s_], prof_[s_]); } while (0)
+#else
+#define SLIP_STAMP(slot) do { } while (0)
+#define SLIP_STAMP_INIT() do { } while (0)
+#define SLIP_STAMP_FLUSH(st) do { } while (0)
+#endif
+
+/* LDS layout in 32-bit words */
+#define SLIP_SCRATCH_WAVES 16       /* waves a worker's share of the global scratch is sized for */
+#define SLIP_LDS_VARS      0        /* 64 words of workgroup-shared scalars          */
+#define SLIP_LDS_SCAN      64       /* 128 words: per-wave partials of scans/reductions */
+#define SLIP_LDS_WORK      192      /* work lists: 2 x SLIP_WORK_CAP (m, i) pairs, or 1 x rows + 1 x 5-word row records */
+#define SLIP_WORK_CAP      512
+#define SLIP_WORK_WORDS    (6 * SLIP_WORK_CAP)
+#define SLIP_LDS_TAB       (SLIP_LDS_WORK + SLIP_WORK_WORDS)   /* column table: row, len, bits, slab offset per pattern entry */
+#define SLIP_TAB_CAP       1024
+#define SLIP_PAT_CAP       1024     /* a pattern of at most this many entries stays in LDS               */
+#define SLIP_LDS_PAT       (SLIP_LDS_TAB + 4 * SLIP_TAB_CAP)
+#define SLIP_LDS_ROWS      (SLIP_LDS_PAT + SLIP_PAT_CAP)     /* row id of every pattern entry (same cap)        */
+#define SLIP_LDS_DIROFF    (SLIP_LDS_ROWS + SLIP_PAT_CAP)    /* slab offset of a row multiplied straight into L */
+#define SLIP_LDS_KEYS      (SLIP_LDS_DIROFF + SLIP_PAT_CAP)  /* leading 64 bits of a row multiplied straight into L */
+#define SLIP_LDS_BITMAP    (SLIP_LDS_KEYS + 2 * SLIP_PAT_CAP)
+
+enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV_F = 5 /* frontier as this worker knows it */,
+       SV_LISTN = 6, SV_TMP = 7,
+       SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14,
+       SV_LALLOC = 16 /* limbs of the L slab handed out to this column's direct rows */, SV_LEXACT = 18,
+       SV_NROWS = 24 /* rows discovered so far (length of rlist) */, SV_K = 25, SV_TAG = 26, SV_ABORT = 27,
+       SV_TMP2 = 28, SV_F2 = 29 /* ready frontier as this worker knows it */ };
+
+SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
+SLIP_DEV int slip_abs(int32_t v) { return v < 0 ? -v : v; }
+SLIP_DEV int slip_limbs(int32_t slen) { return (slip_abs(slen) + 1) >> 1; }
+
+SLIP_DEV uint64_t slip_shfl_up_u64(uint64_t v, int d)
+{
+    int l = slip_lane(), s = l - d;
+    return slip_shfl_u64(v, s < 0 ? l : s);
+}
+
+/* maximum over the lanes of a wave (all lanes call) */
+SLIP_DEV int slip_wave_max_i32(int v)
+{
+    const int lane = slip_lane();
+    for (int d = 32; d >= 1; d >>= 1) { const int o = (int) slip_shfl_u32((uint32_t) v, lane ^ d); if (o > v) v = o; }
+    return v;
+}
+
+/* exclusive prefix sums of two values over the workgroup's threads; totals returned */
+SLIP_DEV void slip_block_scan2(uint64_t a, uint64_t b, uint64_t *tmp, uint64_t *ea, uint64_t *eb,
+                               uint64_t *ta, uint64_t *tb)
+{
+    const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    uint64_t ia = a, ib = b;
+    for (int d = 1; d < SLIP_WAVE; d <<= 1) {
+        uint64_t x = slip_shfl_up_u64(ia, d), y = slip_shfl_up_u64(ib, d);
+        if (lane >= d) { ia += x; ib += y; }
+    }
+    if (lane == SLIP_WAVE - 1) { tmp[2 * wave] = ia; tmp[2 * wave + 1] = ib; }
+    slip_block_sync();
+    uint64_t ba = 0, bb = 0, sa = 0, sb = 0;
+    for (int w = 0; w < nw; w++) {
+        uint64_t x = tmp[2 * w], y = tmp[2 * w + 1];
+        if (w < wave) { ba += x; bb += y; }
+        sa += x; sb += y;
+    }
+    slip_block_sync();
+    *ea = ba + ia - a; *eb = bb + ib - b; *ta = sa; *tb = sb;
+}
+
+/* the same for two counts whose totals stay below 2^32: both travel in one 64-bit word (half the shuffles) */
+SLIP_DEV void slip_block_scan2_small(uint32_t a, uint32_t b, uint64_t *tmp, uint32_t *ea, uint32_t *eb, uint32_t *ta, uint32_t *tb)
+{
+    const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    const uint64_t v = (uint64_t) a | ((uint64_t) b << 32);
+    uint64_t iv = v;
+    for (int d = 1; d < SLIP_WAVE; d <<= 1) {
+        const uint64_t x = slip_shfl_up_u64(iv, d);
+        if (lane >= d) iv += x;
+    }
+    if (lane == SLIP_WAVE - 1) tmp[wave] = iv;
+    slip_block_sync();
+    uint64_t before = 0, total = 0;
+    for (int w = 0; w < nw; w++) { const uint64_t x = tmp[w]; if (w < wave) before += x; total += x; }
+    slip_block_sync();
+    const uint64_t ex = before + iv - v;
+    *ea = (uint32_t) ex; *eb = (uint32_t)(ex >> 32); *ta = (uint32_t) total; *tb = (uint32_t)(total >> 32);
+}
+
+/* workgroup minimum of a 64-bit key (all threads get it) */
+SLIP_DEV uint64_t slip_block_min_u64(uint64_t v, uint64_t *tmp)
+{
+    const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint64_t o = slip_shfl_u64(v, lane ^ d);
+        if (o < v) v = o;
+    }
+    if (lane == 0) tmp[wave] = v;
+    slip_block_sync();
+    uint64_t r = tmp[0];
+    for (int w = 1; w < nw; w++) { uint64_t t = tmp[w]; if (t < r) r = t; }
+    slip_block_sync();
+    return r;
+}
+
+/* workgroup sum of four 64-bit counters (thread 0's view is complete; others too) */
+SLIP_DEV void slip_block_sum4(unsigned long long v[4], uint64_t *tmp)
+{
+    const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    for (int q = 0; q < 4; q++)
+        for (int d = 32; d >= 1; d >>= 1) v[q] += slip_shfl_u64(v[q], lane ^ d);
+    if (lane == 0) for (int q = 0; q < 4; q++) tmp[4 * wave + q] = v[q];
+    slip_block_sync();
+    for (int q = 0; q < 4; q++) { unsigned long long s = 0; for (int w = 0; w < nw; w++) s += tmp[4 * w + q]; v[q] = s; }
+    slip_block_sync();
+}
+
+/* next set bit of the position bitmap in [from, limit), or -1 (wave-cooperative) */
+SLIP_DEV int slip_bitmap_next(const uint32_t *bm, int from, int limit)
+{
+    const int lane = slip_lane();
+    if (from >= limit) return -1;
+    int w = from >> 5;
+    const int wend = (limit + 31) >> 5;
+    int first = 1;
+    while (w < wend) {
+        int idx = w + lane;
+        uint32_t word = idx < wend ? bm[idx] : 0u;
+        if (first && lane == 0) word &= 0xFFFFFFFFu << (from & 31);
+        if (idx == wend - 1 && (limit & 31)) word &= (1u << (limit & 31)) - 1u;
+        uint64_t nz = slip_ballot(word != 0);
+        if (nz) {
+            int t = slip_ctz64(nz);
+            uint32_t wv = slip_shfl_u32(word, t);
+            return (w + t) * 32 + slip_ctz32(wv);
+        }
+        w += SLIP_WAVE; first = 0;
+    }
+    return -1;
+}
+
+/* previous set bit of the bitmap strictly below `from`, or -1 (wave-cooperative) */
+SLIP_DEV int slip_bitmap_prev(const uint32_t *bm, int from)
+{
+    const int lane = slip_lane();
+    if (from <= 0) return -1;
+    int whi = (from - 1) >> 5;                    /* highest word that can hold a candidate */
+    int first = 1;
+    while (whi >= 0) {
+        const int idx = whi - lane;
+        uint32_t word = idx >= 0 ? bm[idx] : 0u;
+        if (first && lane == 0 && (from & 31)) word &= (1u << (from & 31)) - 1u;
+        const uint64_t nz = slip_ballot(word != 0);
+        if (nz) {
+            const int t = slip_ctz64(nz);          /* lowest lane = highest word */
+            const uint32_t wv = slip_shfl_u32(word, t);
+            return (whi - t) * 32 + 31 - slip_clz32(wv);
+        }
+        whi -= SLIP_WAVE; first = 0;
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------ */
+/* shared records: every field through sc1 loads / stores              */
+/* ------------------------------------------------------------------ */
+SLIP_DEV SlipPiv slip_ld_piv(const SlipPiv *p)
+{
+    const uint64_t *w = (const uint64_t *) p;
+    const uint64_t w0 = slip_ld_u64(w), w1 = slip_ld_u64(w + 1), w2 = slip_ld_u64(w + 2), w3 = slip_ld_u64(w + 3), w4 = slip_ld_u64(w + 4);
+    SlipPiv r;
+    r.off = (int64_t) w0; r.len = (int32_t)(uint32_t) w1; r.bits = (int32_t)(uint32_t)(w1 >> 32);
+    r.lo = w2; r.ctz = (int32_t)(uint32_t) w3; r.invlen = (int32_t)(uint32_t)(w3 >> 32); r.inv64 = w4; r.pad = 0;
+    return r;
+}
+SLIP_DEV void slip_st_piv(SlipPiv *p, const SlipPiv &v)
+{
+    uint64_t *w = (uint64_t *) p;
+    slip_st_u64(w, (uint64_t) v.off);
+    slip_st_u64(w + 1, (uint64_t)(uint32_t) v.len | ((uint64_t)(uint32_t) v.bits << 32));
+    slip_st_u64(w + 2, v.lo);
+    slip_st_u64(w + 3, (uint64_t)(uint32_t) v.ctz | ((uint64_t)(uint32_t) v.invlen << 32));
+    slip_st_u64(w + 4, v.inv64);
+}
+SLIP_DEV SlipEnt slip_ld_ent(const SlipEnt *p)
+{
+    const uint64_t *w = (const uint64_t *) p;
+    const uint64_t w0 = slip_ld_u64(w), w1 = slip_ld_u64(w + 1);
+    SlipEnt r; r.off = (int64_t) w0; r.len = (int32_t)(uint32_t) w1; r.bits = (int32_t)(uint32_t)(w1 >> 32);
+    return r;
+}
+SLIP_DEV void slip_st_ent(SlipEnt *p, const SlipEnt &v)
+{
+    uint64_t *w = (uint64_t *) p;
+    slip_st_u64(w, (uint64_t) v.off);
+    slip_st_u64(w + 1, (uint64_t)(uint32_t) v.len | ((uint64_t)(uint32_t) v.bits << 32));
+}
+SLIP_DEV int32_t slip_piv_invlen(const SlipPiv *p) { return slip_ld_i32(&p->invlen); }
+
+SLIP_DEV const dig_t *slip_piv_digits(const SlipParams &P, const SlipPiv &pv) { return (const dig_t *)(P.Llimbs + pv.off); }
+
+SLIP_DEV SlipPiv slip_piv_none(void)
+{
+    SlipPiv p; p.off = 0; p.len = 0; p.bits = 0; p.lo = 1; p.ctz = 0; p.invlen = 0; p.inv64 = 1; p.pad = 0;
+    return p;
+}
+
+/* register loads / stores of big integers by kind of memory:
+ *   _s: shared during the launch (L slab, inverse cache): sc1
+ *   _g: this worker's own global data (its x rows): plain global */
+template <int D> SLIP_DEV WR<D> wr_load_s(const dig_t *p, int len)
+{
+    const int lane = slip_lane();
+    WR<D> x;
+#pragma unroll
+    for (int q = 0; q < D; q++) { const int c = 64 * q + lane; x.d[q] = c < len ? slip_ld_u32(p + c) : 0u; }
+    return x;
+}
+template <int D> SLIP_DEV void wr_store_s(dig_t *p, const WR<D> &x, int count)
+{
+    const int lane = slip_lane();
+#pragma unroll
+    for (int q = 0; q < D; q++) { const int c = 64 * q + lane; if (c < count) slip_st_u32(p + c, x.d[q]); }
+}
+template <int D> SLIP_DEV WR<D> wr_load_g(const dig_t *p, int len)
+{
+    const int lane = slip_lane();
+    WR<D> x;
+#pragma unroll
+    for (int q = 0; q < D; q++) { const int c = 64 * q + lane; x.d[q] = c < len ? slip_gld_u32(p + c) : 0u; }
+    return x;
+}
+template <int D> SLIP_DEV void wr_store_g(dig_t *p, const WR<D> &x, int count)
+{
+    const int lane = slip_lane();
+#pragma unroll
+    for (int q = 0; q < D; q++) { const int c = 64 * q + lane; if (c < count) slip_gst_u32(p + c, x.d[q]); }
+}
+
+/* copy `count` digits of shared data into wave scratch (for the routines that index operands freely) */
+SLIP_DEV void slip_stage_shared(dig_t *dst, const dig_t *src, int count)
+{
+    for (int c = slip_lane(); c < count; c += SLIP_WAVE) dst[c] = slip_ld_u32(src + c);
+    slip_wave_sync();
+}
+
+/* ------------------------------------------------------------------ */
+/* in-lane arithmetic for one-limb operands (results up to 127 bits)   */
+/* ------------------------------------------------------------------ */
+SLIP_DEV int slip_bits128(slip_u128 v)
+{
+    uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t) v;
+    return hi ? 128 - slip_clz64(hi) : (lo ? 64 - slip_clz64(lo) : 0);
+}
+SLIP_DEV uint64_t slip_inv64(uint64_t d)            /* d odd */
+{
+    uint64_t x = d;
+    x *= 2 - d * x; x *= 2 - d * x; x *= 2 - d * x; x *= 2 - d * x; x *= 2 - d * x;
+    return x;
+}
+/* v / d exactly, v < 2^128, d a one-limb divisor with ctz z and 64-bit inverse of its odd part */
+SLIP_DEV slip_u128 slip_divexact128(slip_u128 v, uint64_t d, int z, uint64_t inv64)
+{
+    const uint64_t dodd = d >> z;
+    slip_u128 inv = (slip_u128) inv64;
+    inv = inv * ((slip_u128) 2 - (slip_u128) dodd * inv);          /* 128-bit inverse by one Newton step */
+    return (v >> z) * inv;
+}
+/* the 64-bit magnitude of a value of at most 2 digits, read as one aligned limb (private x row) */
+SLIP_DEV uint64_t slip_limb0(const dig_t *p) { return *(const uint64_t *) p; }
+/* the same from shared data (L slab) */
+SLIP_DEV uint64_t slip_limb0_s(const dig_t *p) { return slip_ld_u64((const uint64_t *) p); }
+
+/* store a value of at most 4 digits (magnitude mag, sign sgn) as row i of the private vector */
+SLIP_DEV void slip_store_small(const SlipParams &P, int i, slip_u128 mag, int sgn, int h, int tag)
+{
+    const int bits = slip_bits128(mag), len = (bits + 31) >> 5;
+    uint64_t *X = (uint64_t *)(P.xd + (int64_t) i * P.xcap);
+    X[0] = (uint64_t) mag;
+    if (len > 2) X[1] = (uint64_t)(mag >> 64);
+    SlipRow r; r.len = sgn < 0 ? -len : len; r.h = h; r.bits = bits; r.tag = tag;
+    P.xrow[i] = r;
+}
+
+/* ------------------------------------------------------------------ */
+/* wave-level pieces                                                    */
+/* ------------------------------------------------------------------ */
+/* Shared inverse cache: inv(rho_p >> ctz) modulo B^invlen at invd[p*invcap].  Any worker may extend it: the
+ * digits of a 2-adic inverse are unique, so concurrent extensions store identical values; a writer drains
+ * its sc1 stores before it raises invlen (atomic max), a reader loads invlen first. */
+
+/* Operands wider than 256 digits go through the routines of wave_bigint.h, which index memory freely with
+ * plain accesses.  For these (rare, long) items the visibility rules are met with fences instead of sc1
+ * accesses: an agent-scope acquire (L1 invalidate) before shared data is read, an agent-scope release (L2
+ * write-back) after the inverse cache has been extended. */
+SLIP_DEV int slip_ensure_inv(const SlipParams &P, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    int have = (int) slip_shfl_u32((uint32_t) slip_piv_invlen(&P.piv[p]), 0);
+    slip_agent_acquire();                     /* digits below `have` (and, if enough, all we need) are readable now */
+    if (have >= want) return 0;
+    if (want > P.invcap || want > P.wcap) return 1;
+    int target = 2 * have > want ? 2 * have : want;
+    if (target > P.invcap) target = P.invcap;
+    if (target > P.wcap) target = P.wcap;
+    const SlipPiv pv = slip_ld_piv(&P.piv[p]);
+    const int ld = slip_abs(pv.len), z = pv.ctz;
+    int lodd = ld - (z >> 5);
+    if (lodd > target) lodd = target;
+    wb_copy_shr(b0, slip_piv_digits(P, pv), ld, z, lodd);
+    dig_t *inv = P.invd + (int64_t) p * P.invcap;
+    wb_inv_extend(inv, have, target, b0, lodd, b1, b2);
+    slip_vm_drain();
+    slip_agent_release();
+    if (slip_lane() == 0) slip_agent_max_i32(&P.piv[p].invlen, target);
+    slip_wave_sync();
+    return 0;
+}
+
+/* store a W-digit result (normalising, zero padded to whole limbs) as row i; 1 if it does not fit */
+SLIP_DEV int slip_store_x(const SlipParams &P, int i, const dig_t *q, int W, int sign, int h, int tag)
+{
+    const int lane = slip_lane();
+    const int len = wb_len(q, W);
+    if (len > P.xcap) return 1;
+    dig_t *X = P.xd + (int64_t) i * P.xcap;
+    const int lw = (len + 1) & ~1;
+    for (int c = lane; c < lw; c += SLIP_WAVE) X[c] = c < len ? q[c] : 0u;
+    if (lane == 0) {
+        SlipRow r; r.len = sign < 0 ? -len : len; r.h = h; r.tag = tag;
+        r.bits = len ? 32 * len - slip_clz32(q[len - 1]) : 0;
+        P.xrow[i] = r;
+    }
+    slip_wave_sync();
+    return 0;
+}
+
+/* ---- register-resident versions (operands of at most 64*D digits; wave_bigint_reg.h) ---- */
+
+/* cached inverse of pivot p's odd part to `want` digits, register Newton; b0: scratch for wide shifts */
+template <int D> SLIP_DEV int slip_ensure_inv_reg(const SlipParams &P, int p, int want, dig_t *b0)
+{
+    int have = (int) slip_shfl_u32((uint32_t) slip_piv_invlen(&P.piv[p]), 0);
+    if (have >= want) return 0;
+    if (want > P.invcap) return 1;
+    int target = 2 * have > want ? 2 * have : want;
+    if (target > P.invcap) target = P.invcap;
+    if (target > 64 * D) target = 64 * D;
+    const SlipPiv pv = slip_ld_piv(&P.piv[p]);
+    const int ld = slip_abs(pv.len);
+    WR<D> dodd;
+    if (ld > 64 * D) {               /* the shift must see the digits above the register window */
+        const dig_t *src = slip_piv_digits(P, pv);
+        const int sw = pv.ctz >> 5, sb = pv.ctz & 31, lane = slip_lane();
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            const int idx = 64 * q + lane + sw;
+            const uint32_t lo = idx < ld ? slip_ld_u32(src + idx) : 0u, hi = idx + 1 < ld ? slip_ld_u32(src + idx + 1) : 0u;
+            dodd.d[q] = sb ? ((lo >> sb) | (hi << (32 - sb))) : lo;
+        }
+    } else dodd = wr_shr<D>(wr_load_s<D>(slip_piv_digits(P, pv), ld), pv.ctz, b0);
+    dig_t *inv = P.invd + (int64_t) p * P.invcap;
+    WR<D> V = wr_inv_extend<D>(wr_load_s<D>(inv, have), have, target, dodd);
+    wr_store_s<D>(inv, V, target);
+    slip_vm_drain();
+    if (slip_lane() == 0) slip_agent_max_i32(&P.piv[p].invlen, target);
+    slip_wave_sync();
+    return 0;
+}
+
+/* store the low digits of q (normalising, padded to whole limbs) as row i */
+template <int D> SLIP_DEV int slip_store_x_reg(const SlipParams &P, int i, const WR<D> &q, int sign, int h, int tag)
+{
+    const int len = wr_len<D>(q);
+    if (len > P.xcap) return 1;
+    dig_t *X = P.xd + (int64_t) i * P.xcap;
+    wr_store_g<D>(X, q, (len + 1) & ~1);                 /* digits above len are zero in q */
+    const uint32_t top = len ? wr_digit<D>(q, len - 1) : 0u;
+    if (slip_lane() == 0) {
+        SlipRow r; r.len = sign < 0 ? -len : len; r.h = h; r.tag = tag;
+        r.bits = len ? 32 * len - slip_clz32(top) : 0;
+        P.xrow[i] = r;
+    }
+    slip_wave_sync();
+    return 0;
+}
+
+/* make the cached inverse of pivot p cover `want` digits, with whichever arithmetic fits the width */
+SLIP_DEV int slip_ensure_inv_any(const SlipParams &P, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    if (want <= 64)  return slip_ensure_inv_reg<1>(P, p, want, b0);
+    if (want <= 128) return slip_ensure_inv_reg<2>(P, p, want, b0);
+    if (want <= 192) return slip_ensure_inv_reg<3>(P, p, want, b0);
+    if (want <= 256) return slip_ensure_inv_reg<4>(P, p, want, b0);
+    return slip_ensure_inv(P, p, want, b0, b1, b2);
+}
+
+/* History update of row r (slip_REF_triangular_solve.c:139-149, 248-257), one wavefront:
+ *     x[r] <- x[r] * rho[pm] / rho[pd]      (pd < 0: no division); the history tag is kept */
+template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, int pm, int pd, dig_t *b0)
+{
+    const SlipRow xr = P.xrow[r];
+    const int lx = slip_abs(xr.len);
+    const SlipPiv m = slip_ld_piv(&P.piv[pm]);
+    const int lm = slip_abs(m.len);
+    int sign = slip_sgn(xr.len) * slip_sgn(m.len);
+    if (pd >= 0) {
+        const SlipPiv d = slip_ld_piv(&P.piv[pd]);
+        const int W = (xr.bits + m.bits - d.bits + 1 + 31) >> 5;
+        { const int e = slip_ensure_inv_reg<D>(P, pd, W, b0); if (e) return e; }
+        WR<D> X = wr_load_g<D>(P.xd + (int64_t) r * P.xcap, lx), M = wr_load_s<D>(slip_piv_digits(P, m), lm);
+        WR<D> Y = lx <= lm ? wr_mul<D>(X, lx < 64 * D ? lx : 64 * D, M) : wr_mul<D>(M, lm < 64 * D ? lm : 64 * D, X);
+        Y = wr_mask<D>(wr_shr<D>(Y, d.ctz, b0), W);
+        WR<D> I = wr_load_s<D>(P.invd + (int64_t) pd * P.invcap, W);
+        Y = wr_mask<D>(wr_mul<D>(I, W, Y), W);
+        return slip_store_x_reg<D>(P, r, Y, sign * slip_sgn(d.len), xr.h, xr.tag);
+    }
+    WR<D> X = wr_load_g<D>(P.xd + (int64_t) r * P.xcap, lx), M = wr_load_s<D>(slip_piv_digits(P, m), lm);
+    WR<D> Y = lx <= lm ? wr_mul<D>(X, lx, M) : wr_mul<D>(M, lm, X);
+    return slip_store_x_reg<D>(P, r, Y, sign, xr.h, xr.tag);
+}
+
+SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    const SlipRow xr = P.xrow[r];
+    const int lx = slip_abs(xr.len);
+    const dig_t *X = P.xd + (int64_t) r * P.xcap;
+    const SlipPiv m = slip_ld_piv(&P.piv[pm]);
+    const int lm = slip_abs(m.len);
+    int sign = slip_sgn(xr.len) * slip_sgn(m.len);
+    int bq = xr.bits + m.bits;
+    {
+        /* widths: W digits of result; the shifted product needs W + ceil(ctz/32) */
+        int Wn = (bq + 31) >> 5;
+        if (pd >= 0) { const SlipPiv d0 = slip_ld_piv(&P.piv[pd]); Wn = ((bq - d0.bits + 1 + 31) >> 5) + ((d0.ctz + 31) >> 5); }
+        if (Wn > P.wcap) return 1;
+        if (Wn <= 64)  return slip_history_wave_reg<1>(P, r, pm, pd, b0);
+        if (Wn <= 128) return slip_history_wave_reg<2>(P, r, pm, pd, b0);
+        if (Wn <= 192) return slip_history_wave_reg<3>(P, r, pm, pd, b0);
+        if (Wn <= 256) return slip_history_wave_reg<4>(P, r, pm, pd, b0);
+    }
+    /* wide operands (see slip_ensure_inv) */
+    slip_agent_acquire();
+    if (pd < 0) {
+        const int W = (bq + 31) >> 5;
+        if (W > P.wcap) return 1;
+        wb_mul_lo(b0, X, lx, slip_piv_digits(P, m), lm, W);
+        return slip_store_x(P, r, b0, W, sign, xr.h, xr.tag);
+    }
+    const SlipPiv d = slip_ld_piv(&P.piv[pd]);
+    bq -= d.bits - 1;
+    const int W = (bq + 31) >> 5, zh = d.ctz, W2 = W + ((zh + 31) >> 5);
+    if (W2 > P.wcap) return 1;
+    { const int e = slip_ensure_inv(P, pd, W, b0, b1, b2); if (e) return e; }
+    wb_mul_lo(b0, X, lx, slip_piv_digits(P, m), lm, W2);
+    wb_copy_shr(b1, b0, W2, zh, W);
+    wb_mul_lo(b2, b1, W, P.invd + (int64_t) pd * P.invcap, W, W);
+    return slip_store_x(P, r, b2, W, sign * slip_sgn(d.len), xr.h, xr.tag);
+}
+
+/* One IPGE update (slip_REF_triangular_solve.c:156-241) of target row i by source row j
+ * (pivot position jn) through the L entry m, one wavefront, everything modulo B^W:
+ *     x[i] <- ( hist(x[i]) * rho[jn] - L_m * x[j] ) / rho[jn-1]                          */
+struct SlipIpgePlan { int W, W1, W2, hist, hdiv, has_d; };
+
+/* bit bounds -> working widths of one IPGE update (scalar code) */
+SLIP_DEV SlipIpgePlan slip_ipge_plan(const SlipParams &P, const SlipRow &xi, const SlipRow &xj, const SlipEnt &le,
+                                     const SlipPiv &R, int jn)
+{
+    SlipIpgePlan pl;
+    const int lx = slip_abs(xi.len), hi = xi.h, br = R.bits;
+    pl.has_d = jn >= 1;
+    int bd = 0, zd = 0;
+    if (pl.has_d) { const SlipPiv Dd = slip_ld_piv(&P.piv[jn - 1]); bd = Dd.bits; zd = Dd.ctz; }
+    pl.hist = lx != 0 && pl.has_d && hi < jn - 1;
+    pl.hdiv = pl.hist && hi > -1;
+    int bh = 0, zh = 0;
+    if (pl.hdiv) { const SlipPiv H = slip_ld_piv(&P.piv[hi]); bh = H.bits; zh = H.ctz; }
+    const int bxp = !lx ? 0 : (!pl.hist ? xi.bits : (pl.hdiv ? xi.bits + bd - bh + 1 : xi.bits + bd));
+    const int b1b = lx ? bxp + br : 0, b2b = le.bits + xj.bits;
+    const int bnum = (b1b > b2b ? b1b : b2b) + 1;
+    const int bq = pl.has_d ? bnum - bd + 1 : bnum;
+    pl.W = (bq + 1 + 31) >> 5;                       /* + sign bit */
+    pl.W1 = pl.W + (pl.has_d ? ((zd + 31) >> 5) : 0);
+    pl.W2 = pl.W1 + (pl.hdiv ? ((zh + 31) >> 5) : 0);
+    return pl;
+}
+
+template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int j, int jn, int64_t m, dig_t *b0,
+                                                 const SlipRow &xi, const SlipRow &xj, const SlipEnt &le, const SlipPiv &R,
+                                                 int W, int W1, int hist, int hdiv)
+{
+    const int has_d = jn >= 1;
+    const int lx = slip_abs(xi.len);
+    SlipPiv Dv = slip_piv_none();
+    if (has_d) Dv = slip_ld_piv(&P.piv[jn - 1]);
+    if (hdiv) { const int e = slip_ensure_inv_reg<D>(P, xi.h, W1, b0); if (e) return e; }
+    if (has_d) { const int e = slip_ensure_inv_reg<D>(P, jn - 1, W, b0); if (e) return e; }
+    const int CAP = 64 * D;
+    const int lr = slip_abs(R.len) < W1 ? slip_abs(R.len) : W1;
+    WR<D> Rr = wr_load_s<D>(slip_piv_digits(P, R), lr);
+    /* P1 = hist(x_i) * rho_jn  (mod B^W1), sign s1 */
+    int s1 = slip_sgn(xi.len) * slip_sgn(R.len);
+    WR<D> P1 = wr_zero<D>();
+    if (lx) {
+        const int lxe = lx < CAP ? lx : CAP;
+        WR<D> Y = wr_load_g<D>(P.xd + (int64_t) i * P.xcap, lxe);
+        int ly = lxe;
+        if (hist) {
+            const int ld = slip_abs(Dv.len) < CAP ? slip_abs(Dv.len) : CAP;
+            WR<D> Dd = wr_load_s<D>(slip_piv_digits(P, Dv), ld);
+            Y = ly <= ld ? wr_mul<D>(Y, ly, Dd) : wr_mul<D>(Dd, ld, Y);
+            s1 *= slip_sgn(Dv.len);
+            ly = W1;
+            if (hdiv) {
+                const SlipPiv H = slip_ld_piv(&P.piv[xi.h]);
+                Y = wr_mask<D>(wr_shr<D>(Y, H.ctz, b0), W1);
+                WR<D> IH = wr_load_s<D>(P.invd + (int64_t) xi.h * P.invcap, W1);
+                Y = wr_mul<D>(IH, W1, Y);
+                s1 *= slip_sgn(H.len);
+            }
+            Y = wr_mask<D>(Y, W1);
+        }
+        P1 = ly <= lr ? wr_mul<D>(Y, ly, Rr) : wr_mul<D>(Rr, lr, Y);
+    }
+    /* P2 = L_m * x_j, sign s2 */
+    const int ll = slip_abs(le.len) < W1 ? slip_abs(le.len) : W1, lj = slip_abs(xj.len) < W1 ? slip_abs(xj.len) : W1;
+    WR<D> Lm = wr_load_s<D>((const dig_t *)(P.Llimbs + le.off), ll), Xj = wr_load_g<D>(P.xd + (int64_t) j * P.xcap, lj);
+    WR<D> P2 = ll <= lj ? wr_mul<D>(Lm, ll, Xj) : wr_mul<D>(Xj, lj, Lm);
+    const int s2 = slip_sgn(le.len) * slip_sgn(xj.len);
+    /* T = s1*P1 - s2*P2 (mod B^W1) */
+    int sT;
+    WR<D> T;
+    if (!lx)           { T = wr_addsub<D>(wr_zero<D>(), P2, 1); sT = s2; }
+    else if (s1 == s2) { T = wr_addsub<D>(P1, P2, 1); sT = s1; }
+    else               { T = wr_addsub<D>(P1, P2, 0); sT = s1; }
+    T = wr_mask<D>(T, W1);
+    if (has_d) {
+        T = wr_mask<D>(wr_shr<D>(T, Dv.ctz, b0), W);
+        WR<D> ID = wr_load_s<D>(P.invd + (int64_t)(jn - 1) * P.invcap, W);
+        T = wr_mask<D>(wr_mul<D>(ID, W, T), W);
+        sT *= slip_sgn(Dv.len);
+    }
+    if (wr_digit<D>(T, W - 1) >> 31) { T = wr_mask<D>(wr_addsub<D>(wr_zero<D>(), T, 1), W); sT = -sT; }
+    (void) m;
+    return slip_store_x_reg<D>(P, i, T, sT, jn, xi.tag);
+}
+
+SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    const SlipRow xi = P.xrow[i], xj = P.xrow[j];
+    const SlipEnt le = slip_ld_ent(&P.Le[m]);
+    const SlipPiv R = slip_ld_piv(&P.piv[jn]);
+    const int lx = slip_abs(xi.len), sx = slip_sgn(xi.len);
+    const dig_t *X = P.xd + (int64_t) i * P.xcap;
+    const int lr = slip_abs(R.len), sr = slip_sgn(R.len);
+    const int ll = slip_abs(le.len), sl = slip_sgn(le.len);
+    const dig_t *Lm = (const dig_t *)(P.Llimbs + le.off);
+    const int lj = slip_abs(xj.len), sj = slip_sgn(xj.len);
+    const dig_t *Xj = P.xd + (int64_t) j * P.xcap;
+    const int hi = xi.h;
+    const SlipIpgePlan pl = slip_ipge_plan(P, xi, xj, le, R, jn);
+    const int has_d = pl.has_d, hist = pl.hist, hdiv = pl.hdiv, W = pl.W, W1 = pl.W1, W2 = pl.W2;
+    if (W2 > P.wcap) return 1;
+    /* operands that fit 256 digits stay in registers */
+    if (W2 <= 64)  return slip_ipge_wave_reg<1>(P, i, j, jn, m, b0, xi, xj, le, R, W, W1, hist, hdiv);
+    if (W2 <= 128) return slip_ipge_wave_reg<2>(P, i, j, jn, m, b0, xi, xj, le, R, W, W1, hist, hdiv);
+    if (W2 <= 192) return slip_ipge_wave_reg<3>(P, i, j, jn, m, b0, xi, xj, le, R, W, W1, hist, hdiv);
+    if (W2 <= 256) return slip_ipge_wave_reg<4>(P, i, j, jn, m, b0, xi, xj, le, R, W, W1, hist, hdiv);
+    SlipPiv D = slip_piv_none();
+    if (has_d) D = slip_ld_piv(&P.piv[jn - 1]);
+    const int ld = slip_abs(D.len), sd = has_d ? slip_sgn(D.len) : 1, zd = D.ctz;
+    int zh = 0, sh = 1;
+    if (hdiv) { const SlipPiv H = slip_ld_piv(&P.piv[hi]); zh = H.ctz; sh = slip_sgn(H.len); }
+    if (hdiv) { const int e = slip_ensure_inv(P, hi, W1, b0, b1, b2); if (e) return e; }
+    if (has_d) { const int e = slip_ensure_inv(P, jn - 1, W, b0, b1, b2); if (e) return e; }
+    slip_agent_acquire();                      /* wide operands (see slip_ensure_inv): plain loads from here on */
+    /* P1 = hist(x_i) * rho_jn  -> b1, sign s1 */
+    int s1 = sx * sr;
+    if (lx == 0) {
+        /* handled below */
+    } else if (!hist) {
+        wb_mul_lo(b1, X, lx, slip_piv_digits(P, R), lr, W1);
+    } else if (!hdiv) {
+        wb_mul_lo(b0, X, lx, slip_piv_digits(P, D), ld, W1);
+        wb_mul_lo(b1, b0, W1, slip_piv_digits(P, R), lr, W1);
+        s1 *= sd;
+    } else {
+        wb_mul_lo(b0, X, lx, slip_piv_digits(P, D), ld, W2);
+        wb_copy_shr(b1, b0, W2, zh, W1);
+        wb_mul_lo(b0, b1, W1, P.invd + (int64_t) hi * P.invcap, W1, W1);
+        wb_mul_lo(b1, b0, W1, slip_piv_digits(P, R), lr, W1);
+        s1 *= sd * sh;
+    }
+    /* P2 = L_m * x_j -> b2, sign s2 */
+    const int s2 = sl * sj;
+    wb_mul_lo(b2, Lm, ll, Xj, lj, W1);
+    /* T = s1*P1 - s2*P2 = sT * (P1 -/+ P2)  -> b1 */
+    int sT;
+    if (lx == 0)       { wb_addsub(b1, (const dig_t *) 0, 0, b2, W1, W1, 1, 0u); sT = s2; }
+    else if (s1 == s2) { wb_addsub(b1, b1, W1, b2, W1, W1, 1); sT = s1; }
+    else               { wb_addsub(b1, b1, W1, b2, W1, W1, 0); sT = s1; }
+    /* exact division by rho[jn-1] */
+    dig_t *Q = b1;
+    if (has_d) {
+        wb_copy_shr(b0, b1, W1, zd, W);
+        wb_mul_lo(b2, b0, W, P.invd + (int64_t)(jn - 1) * P.invcap, W, W);
+        Q = b2; sT *= sd;
+    }
+    /* two's complement -> sign-magnitude */
+    if (Q[W - 1] >> 31) {
+        wb_addsub(Q, (const dig_t *) 0, 0, Q, W, W, 1, 0u);
+        sT = -sT;
+    }
+    return slip_store_x(P, i, Q, W, sT, jn, xi.tag);
+}
+
+/* is |a| * 2^sa >= |b| * 2^sb ?  a, b normalised and in wave-addressable memory (scratch / private);
+ * scratch b0, b1 of wcap digits */
+SLIP_DEV int slip_ge_shifted(const dig_t *a, int la, int sa, const dig_t *b, int lb, int sb,
+                             dig_t *b0, dig_t *b1, int wcap, int *err)
+{
+    int ba = wb_bits(a, la) + sa, bb = wb_bits(b, lb) + sb;
+    if (ba != bb) return ba > bb;
+    int W = (ba + 31) >> 5;
+    if (W > wcap) { *err = 1; return 0; }
+    wb_copy_shl(b0, a, la, sa, W);
+    wb_copy_shl(b1, b, lb, sb, W);
+    return wb_cmp(b0, W, b1, W) >= 0;
+}
+
+/* in-lane history update  x * rho[pm] / rho[pd]  when everything is one limb; 0 if not applicable */
+SLIP_DEV int slip_history_small(const SlipParams &P, const SlipRow &xr, uint64_t xv, const SlipPiv &m, int pd,
+                                slip_u128 *out, int *osgn)
+{
+    if (slip_abs(xr.len) > 2 || slip_abs(m.len) > 2) return 0;
+    slip_u128 y = (slip_u128) xv * m.lo;
+    int s = slip_sgn(xr.len) * slip_sgn(m.len);
+    if (pd >= 0) {
+        const SlipPiv d = slip_ld_piv(&P.piv[pd]);
+        if (slip_abs(d.len) > 2) return 0;
+        y = slip_divexact128(y, d.lo, d.ctz, d.inv64);
+        s *= slip_sgn(d.len);
+    }
+    *out = y; *osgn = s;
+    return 1;
+}
+
+/* left-aligned leading 64 bits of a normalised l-digit magnitude; shared != 0: the digits live in the L slab */
+SLIP_DEV uint64_t slip_top64(const dig_t *X, int l, int shared)
+{
+    const uint32_t x1 = shared ? slip_ld_u32(X + l - 1) : X[l - 1];
+    const uint32_t x2 = l >= 2 ? (shared ? slip_ld_u32(X + l - 2) : X[l - 2]) : 0u;
+    uint64_t top = ((uint64_t) x1 << 32) | x2;
+    const int sh = slip_clz32(x1);
+    if (sh) {
+        const uint32_t x3 = l >= 3 ? (shared ? slip_ld_u32(X + l - 3) : X[l - 3]) : 0u;
+        top = (top << sh) | (uint64_t)(x3 >> (32 - sh));
+    }
+    return top;
+}
+
+/* compare the magnitudes of two normalised numbers of equal length l that may live in shared memory: -1, 0, +1
+ * (wave-cooperative; all lanes call) */
+SLIP_DEV int slip_cmp_mag(const dig_t *a, int sa, const dig_t *b, int sb, int l)
+{
+    const int lane = slip_lane();
+    for (int base = ((l - 1) >> 6) << 6; base >= 0 && l > 0; base -= SLIP_WAVE) {
+        const int c = base + lane;
+        const uint32_t av = c < l ? (sa ? slip_ld_u32(a + c) : a[c]) : 0u, bv = c < l ? (sb ? slip_ld_u32(b + c) : b[c]) : 0u;
+        const uint64_t df = slip_ballot(av != bv);
+        if (df) {
+            const int t = 63 - slip_clz64(df);
+            const uint32_t at = slip_shfl_u32(av, t), bt = slip_shfl_u32(bv, t);
+            return at > bt ? 1 : -1;
+        }
+    }
+    return 0;
+}
+
+/* rows[t] (one-limb values, never updated: h < 0) times the long pivot M: the pivot's digits stay in
+ * registers, every wave takes rows in turn (slip_REF_triangular_solve.c:248-257 for untouched rows).
+ * rec3: word 3 of the row's record = (pattern index << 3) | (negative << 2) | digits of the one-limb value;
+ * ctab != null (this workgroup's LDS): also enter the row into the column table and its leading 64 bits into the key
+ * list, so that the pivot search does not read back through memory what this CU has just produced */
+template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const SlipPiv &M, const WR<D> &Y, int r, uint32_t rec3, int64_t off,
+                                                   uint32_t slot_off, uint32_t *ctab, uint32_t *ckeys, int tag)
+{
+    const int len = wr_len<D>(Y);
+    wr_store_s<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
+    const uint32_t d1 = len ? wr_digit<D>(Y, len - 1) : 0u;
+    const int neg = (int)((rec3 >> 2) & 1u) ^ (M.len < 0);
+    const int32_t slen = neg ? -len : len;
+    const int bits = len ? 32 * len - slip_clz32(d1) : 0;
+    if (ctab) {
+        const uint32_t d2 = len >= 2 ? wr_digit<D>(Y, len - 2) : 0u, d3 = len >= 3 ? wr_digit<D>(Y, len - 3) : 0u;
+        if (slip_lane() == 0) {
+            uint64_t top = ((uint64_t) d1 << 32) | d2;
+            const int sh = len ? slip_clz32(d1) : 0;
+            if (sh) top = (top << sh) | (uint64_t)(d3 >> (32 - sh));
+            const int pidx = (int)(rec3 >> 3);
+            ctab[0 * SLIP_TAB_CAP + pidx] = (uint32_t) r; ctab[1 * SLIP_TAB_CAP + pidx] = (uint32_t) slen; ctab[2 * SLIP_TAB_CAP + pidx] = (uint32_t) bits;
+            ctab[3 * SLIP_TAB_CAP + pidx] = 0x80000000u | slot_off;
+            ckeys[2 * pidx] = (uint32_t) top; ckeys[2 * pidx + 1] = (uint32_t)(top >> 32);
+        }
+    }
+    if (slip_lane() == 0) {
+        SlipRow nr; nr.len = slen; nr.h = -2;                /* h == -2: never updated (h = -1) AND the value lives in the L slab ... */
+        nr.tag = tag;
+        nr.bits = bits;
+        P.xrow[r] = nr;
+        *(int64_t *)(P.xd + (int64_t) r * P.xcap) = off;     /* ... at this limb offset */
+    }
+}
+
+template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, int md_shared, const uint32_t *recs,
+                                                int first, int stride, int nrows, int64_t slab_base, uint32_t *ctab, uint32_t *ckeys, int tag)
+{
+    const int lane = slip_lane();
+    const WR<D> Mr = md_shared ? wr_load_s<D>(Md, slip_abs(M.len)) : wr_load<D>(Md, slip_abs(M.len));
+    /* record written by the classifying lane: row, low/high digit of the one-limb value, signed length,
+     * and the slot of the L slab reserved for the product (these rows ARE L(:,k): no second copy) */
+    int t = first;
+    /* pairs of one-digit rows (|a| < 2^32, the common case): two carry chains side by side */
+    for (; t + stride < nrows; t += 2 * stride) {
+        const int u = t + stride;
+        const uint32_t w0 = recs[5 * t + 3], w1 = recs[5 * u + 3];
+        if ((w0 & 3u) != 1u || (w1 & 3u) != 1u) break;
+        WR<D> Y0, Y1;
+        wr_mul_digit2<D>(recs[5 * t + 1], recs[5 * u + 1], Mr, Y0, Y1);
+        slip_mul_row_finish<D>(P, M, Y0, (int) recs[5 * t], w0, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag);
+        slip_mul_row_finish<D>(P, M, Y1, (int) recs[5 * u], w1, slab_base + (int64_t) recs[5 * u + 4], recs[5 * u + 4], ctab, ckeys, tag);
+    }
+    for (; t < nrows; t += stride) {
+        const uint32_t w = recs[5 * t + 3];
+        WR<D> Y;
+        if ((w & 3u) == 1u) Y = wr_mul_digit<D>(recs[5 * t + 1], Mr);      /* |a| < 2^32 */
+        else {
+            WR<D> A = wr_zero<D>();
+            if (lane == 0) A.d[0] = recs[5 * t + 1];
+            if (lane == 1) A.d[0] = recs[5 * t + 2];
+            Y = wr_mul<D>(A, (int)(w & 3u), Mr);
+        }
+        slip_mul_row_finish<D>(P, M, Y, (int) recs[5 * t], w, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag);
+    }
+    return 0;
+}
+
+/* rows [first, first+stride, ...) of a column's one-limb-times-pivot list (5-word records), pivot M = rho[k-1];
+ * Md: staged copy of the pivot's digits in LDS (md_shared 0), or the L slab itself (md_shared 1) */
+SLIP_DEV int slip_mul_rows_any(const SlipParams &P, const SlipPiv &M, const dig_t *Md, int md_shared, const uint32_t *recs, int first, int stride, int nrows,
+                               int64_t slab_base, uint32_t *ctab, uint32_t *ckeys, int tag)
+{
+    const int Dm = (slip_abs(M.len) + 2 + 63) >> 6;
+    if (Dm <= 1) return slip_mul_rows_reg<1>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag);
+    if (Dm == 2) return slip_mul_rows_reg<2>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag);
+    if (Dm == 3) return slip_mul_rows_reg<3>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag);
+    return slip_mul_rows_reg<4>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag);
+}
+
+/* ---- REF triangular solves (SLIP_LU_solve.c:41-86): the two extra wave-level operations ---- */
+
+/* x[r] <- x[r] / rho[p], exact (slip_back_sub.c:43: divide by the diagonal of U = the pivot) */
+SLIP_DEV int slip_divexact_wave(const SlipParams &P, int r, int p, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    const SlipRow xr = P.xrow[r];
+    const int lx = slip_abs(xr.len);
+    const SlipPiv d = slip_ld_piv(&P.piv[p]);
+    const int bq = xr.bits - d.bits + 1;
+    const int W = bq > 0 ? (bq + 31) >> 5 : 1, zh = d.ctz, W2 = W + ((zh + 31) >> 5);
+    if (W2 > P.wcap) return 1;
+    { const int e = slip_ensure_inv_any(P, p, W, b0, b1, b2); if (e) return e; }
+    slip_agent_acquire();
+    wb_copy_shr(b1, P.xd + (int64_t) r * P.xcap, lx, zh, W);
+    wb_mul_lo(b2, b1, W, P.invd + (int64_t) p * P.invcap, W, W);
+    return slip_store_x(P, r, b2, W, slip_sgn(xr.len) * slip_sgn(d.len), xr.h, xr.tag);
+}
+
+/* x[i] <- x[i] - U_m * x[j]   (slip_back_sub.c:44-50); the factors are not written during a solve: plain loads */
+SLIP_DEV int slip_submul_wave(const SlipParams &P, int i, int j, int64_t m, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    const SlipRow xi = P.xrow[i], xj = P.xrow[j];
+    const SlipEnt ue = P.Ue[m];
+    const int lx = slip_abs(xi.len), sx = slip_sgn(xi.len);
+    const int bt = (xi.bits > ue.bits + xj.bits ? xi.bits : ue.bits + xj.bits) + 1;
+    const int W = (bt + 1 + 31) >> 5;                       /* + sign bit */
+    if (W > P.wcap) return 1;
+    wb_mul_lo(b2, (const dig_t *)(P.Ulimbs + ue.off), slip_abs(ue.len), P.xd + (int64_t) j * P.xcap, slip_abs(xj.len), W);
+    const int s2 = slip_sgn(ue.len) * slip_sgn(xj.len);
+    if (lx == 0) return slip_store_x(P, i, b2, W, -s2, xi.h, xi.tag);
+    int sT = sx;
+    wb_addsub(b1, P.xd + (int64_t) i * P.xcap, lx, b2, W, W, sx == s2);       /* |x| -/+ |U x_j| */
+    if (sx == s2 && (b1[W - 1] >> 31)) { wb_addsub(b1, (const dig_t *) 0, 0, b1, W, W, 1, 0u); sT = -sT; }
+    (void) b0;
+    return slip_store_x(P, i, b1, W, sT, xi.h, xi.tag);
+}
+
+/* kind 1: IPGE updates of source (j, jn), items = (m - m0, i) pairs; kind 2: history rows of column k (division by rho[h]);
+ * kind 4: x * rho[k-1]; kind 5: back-substitution updates (m - m0, i) of source j */
+SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, int64_t m0, const uint32_t *items, int t,
+                           dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    if (kind == 1) return slip_ipge_wave(P, (int) items[2 * t + 1], j, jn, m0 + (int64_t) items[2 * t], b0, b1, b2);
+    if (kind == 5) return slip_submul_wave(P, (int) items[2 * t + 1], j, m0 + (int64_t) items[2 * t], b0, b1, b2);
+    const int r = (int) items[t];
+    if (kind == 4) return slip_history_wave(P, r, k - 1, -1, b0, b1, b2);      /* x * rho[k-1] */
+    return slip_history_wave(P, r, k - 1, P.xrow[r].h, b0, b1, b2);
+}
+
+/* ---- out-of-line entry points (one copy each; the parameters are the workgroup's LDS copy) ---- */
+SLIP_DEVN int slip_run_item_out(const SlipParams *Pg, int kind, int j, int jn, int k, int64_t m0, const uint32_t *items, int t,
+                                dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    return slip_run_item(*Pg, kind, j, jn, k, m0, items, t, b0, b1, b2);
+}
+SLIP_DEVN int slip_history_wave_out(const SlipParams *Pg, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    return slip_history_wave(*Pg, r, pm, pd, b0, b1, b2);
+}
+SLIP_DEVN int slip_divexact_out(const SlipParams *Pg, int r, int p, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    return slip_divexact_wave(*Pg, r, p, b0, b1, b2);
+}
+/* the exact tolerance test of the diagonal preference: |num| * 2^(-te) >= tol_m * |den|  (slip_get_pivot.c:89-118);
+ * num / den in wave-addressable memory */
+SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int ln, const dig_t *den, int ldn,
+                                   dig_t *b0, dig_t *b1, dig_t *b2, int wcap)     /* 1 / 0, or -1: scratch too small */
+{
+    int err_ = 0, *err = &err_;
+    const int Wm = ldn + 2;
+    if (slip_lane() == 0) { b2[0] = (uint32_t) tol_m; b2[1] = (uint32_t)(tol_m >> 32); }
+    slip_wave_sync();
+    wb_mul_lo(b0, b2, 2, den, ldn, Wm);
+    const int lm_ = wb_len(b0, Wm);
+    for (int c = slip_lane(); c < lm_; c += SLIP_WAVE) b2[c] = b0[c];
+    slip_wave_sync();
+    const int ge = slip_ge_shifted(num, ln, te < 0 ? -te : 0, b2, lm_, te > 0 ? te : 0, b0, b1, wcap, err);
+    return err_ ? -1 : ge;
+}
+
+/* drain a queue of wave-level items with this workgroup's waves; errors land in sv[SV_ERR].
+ * Called by all threads after a workgroup barrier; returns after a workgroup barrier with every item done. */
+SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, int jn, int k, int64_t m0, int nq,
+                         const uint32_t *wl, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    if (!sv[SV_ERR])
+        for (int t = wave; t < nq; t += nw) {
+            const int e = slip_run_item_out(&P, kind, j, jn, k, m0, wl, t, b0, b1, b2);
+            if (e && lane == 0) sv[SV_ERR] = e;
+        }
+    slip_block_sync();
+}
+
+#include "ref_lu_pipe_cols.h"
+
+#endif /* SLIP_REF_LU_PIPE_H */

@@ -1,0 +1,1139 @@
+/* ref_lu_pipe_cols.h -- the column worker: gated sweep, pattern, pivot commit (stage 1), L/U write (stage 2),
+ * and the REF triangular solves on resident factors.  Included by ref_lu_pipe.h (see the design notes there). */
+#ifndef SLIP_REF_LU_PIPE_COLS_H
+#define SLIP_REF_LU_PIPE_COLS_H
+
+/* Spins are bounded by ITERATION counts (each iteration sleeps): a wait that is never answered ends the launch
+ * with SLIPDEV_INTERNAL instead of hanging the device. */
+#define SLIP_SPIN_LIMIT 40000000ull
+#define SLIPDEV_ABORTED 100                 /* internal to the kernel: this worker's column can never commit */
+
+SLIP_DEV void slip_raise_stop(SlipState *st, int k, int status) { slip_agent_min_i64(&st->stop, ((int64_t) k << 8) | (int64_t) status); }
+
+/* Wait until the commit frontier reaches `need` (need <= k).  Called by all threads; returns the frontier, or -1 when
+ * column k can never commit (an earlier column stopped the factorisation, or a wait timed out). */
+SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k)
+{
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    slip_block_sync();
+    if (slip_tid() == 0) {
+        int res;
+        unsigned long long spins = 0;
+        for (;;) {
+            const int F = slip_ld_i32(&st->F);
+            if (F >= need) { res = F; break; }
+            const int64_t stop = slip_ld_i64(&st->stop);
+            if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
+            if (need - F <= 2) slip_sleep_short(); else slip_sleep();
+            if (++spins > SLIP_SPIN_LIMIT) { slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
+        }
+        sv[SV_TMP2] = res;
+    }
+    slip_block_sync();
+    return sv[SV_TMP2];
+}
+
+/* The ready frontier F2: every column below it has published its L entries and limbs (stage 2).  Stage 2 ends out of
+ * order, so F2 is advanced over the per-column flags Lready[] by whoever finds it behind: the worker that has just
+ * finished a column, and any worker that waits for it (so a missed advance cannot strand the pipeline).  All accesses
+ * are returning agent-scope atomics: an advance that follows a flag store in program order also follows it in memory. */
+SLIP_DEV int slip_advance_ready(const SlipParams &P, SlipState *st)
+{
+    int f2 = slip_agent_add_i32(&st->F2, 0);
+    const int F = slip_ld_i32(&st->F);
+    while (f2 < F && slip_agent_add_i32(&P.Lready[f2], 0) != 0) {
+        const int seen = slip_agent_cas_i32(&st->F2, f2, f2 + 1);
+        f2 = seen == f2 ? f2 + 1 : seen;
+    }
+    return f2;
+}
+
+/* Wait until the ready frontier reaches `need` (need <= the commit frontier this worker knows).  Called by all threads;
+ * returns the ready frontier, or -1 when the launch is being given up. */
+SLIP_DEV int slip_wait_ready(const SlipParams &P, SlipState *st, uint32_t *lds, int need)
+{
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    slip_block_sync();
+    if (slip_tid() == 0) {
+        int res;
+        unsigned long long spins = 0;
+        for (;;) {
+            const int f2 = slip_advance_ready(P, st);
+            if (f2 >= need) { res = f2; break; }
+            if ((int)(slip_ld_i64(&st->stop) & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
+            slip_sleep_short();
+            if (++spins > SLIP_SPIN_LIMIT) { slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
+        }
+        sv[SV_TMP2] = res;
+    }
+    slip_block_sync();
+    return sv[SV_TMP2];
+}
+
+/* append this lane's newly discovered row to the worker's row list (slots per wave: one LDS atomic per wave) */
+SLIP_DEV void slip_rlist_push(const SlipParams &P, volatile int32_t *sv, int has, int row)
+{
+    const int lane = slip_lane();
+    const uint64_t nm = slip_ballot(has);
+    int base = 0;
+    if (lane == 0 && nm) base = slip_atomic_add_i32((int32_t *) &sv[SV_NROWS], slip_popc64(nm));
+    base = (int) slip_shfl_u32((uint32_t) base, 0);
+    if (has) P.rlist[base + slip_popc64(nm & ((1ull << lane) - 1ull))] = row;
+}
+
+/* ------------------------------------------------------------------ */
+/* The ascending sweep over the pivotal positions < k of the pattern (slip_REF_triangular_solve.c:124-241).
+ * GATED (a column of the factorisation running ahead of the commit frontier): a source at position jn is
+ * applied once jn is below the frontier this worker knows (sv[SV_F]) and L(:,jn) is published; when no such
+ * source is left and the frontier is still below k the worker waits for it to move and then looks at the rows
+ * that became pivotal meanwhile (row_perm[c] for the new positions c).  Not GATED (k = n, the right-hand side
+ * scattered instead of A(:,col)): the REF forward substitution (slip_forward_sub.c:61-158 is the same
+ * recurrence over all positions) on complete factors.
+ * Called by all threads; returns 1 if the column must be given up; the caller syncs and checks sv[SV_ERR]. */
+template <bool FAST, bool GATED>
+SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const int tag, uint32_t *lds, uint32_t *bm, dig_t *b0, dig_t *b1, dig_t *b2,
+                        unsigned long long &c_read, unsigned long long &c_upd, unsigned long long &c_src, unsigned long long &c_str,
+                        unsigned long long &c_mac)
+{
+    const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    uint32_t *work = lds + SLIP_LDS_WORK;
+    int cur = -1, step = 0;
+    int pj = -1, pjn = -1;                       /* the source whose queued (wave) updates are pending */
+    int dj = -1, dys = 1, dh = -1;               /* finalised one-limb source value not yet written back */
+    slip_u128 dy = 0;
+    for (;; step++) {
+        slip_block_sync();
+        /* write back the previous source's finalised value: every thread has read the old one by now */
+        if (dj >= 0) { if (tid == 0) slip_store_small(P, dj, dy, dys, dh, tag); dj = -1; }
+        /* queued multi-limb updates of the previous source: one wavefront each */
+        const int nq = sv[SV_CNT0 + (step + 2) % 3];
+        if (tid == 0) sv[SV_CNT0 + (step + 1) % 3] = 0;
+        const int Fl = GATED ? sv[SV_F] : k;     /* everything below Fl is final */
+        const int jn = slip_bitmap_next(bm, cur + 1, Fl);
+        if (nq > 0) {
+            slip_block_sync();
+            slip_drain(P, lds, 1, pj, pjn, -1, slip_ld_i64(&P.Lp[pjn]), nq, work + ((step + 1) & 1) * 2 * SLIP_WORK_CAP, b0, b1, b2);
+            if (sv[SV_ERR]) break;
+        }
+        if (jn < 0) {
+            if (!GATED || Fl >= k) break;        /* the sweep is complete */
+            /* wait for the frontier to move; the rows of the pattern that became pivotal are row_perm[c], c in [Fl, Fn) */
+            int Fn = slip_wait_frontier(st, lds, Fl + 1, k);
+            if (Fn < 0) return 1;
+            if (Fn > k) Fn = k;
+            for (int c = Fl + tid; c < Fn; c += T) {
+                const int r = slip_ld_i32(&P.row_perm[c]);
+                if (P.xrow[r].tag == tag) slip_atomic_or_u32(&bm[c >> 5], 1u << (c & 31));
+            }
+            if (tid == 0) sv[SV_F] = Fn;
+            continue;
+        }
+        cur = jn;
+        if (GATED && jn >= sv[SV_F2]) {
+            /* the source is committed but its L column may still be on its way (stage 2 of column jn) */
+            const int f2 = slip_wait_ready(P, st, lds, jn + 1);
+            if (f2 < 0) return 1;
+            if (tid == 0) sv[SV_F2] = f2;
+            slip_block_sync();
+        }
+        const int j = slip_ld_i32(&P.row_perm[jn]);
+        SlipRow xj = P.xrow[j];
+        uint64_t xjv = xj.len != 0 ? slip_limb0(P.xd + (int64_t) j * P.xcap) : 0;
+        const SlipPiv R = slip_ld_piv(&P.piv[jn]);
+        SlipPiv D = slip_piv_none();
+        if (jn >= 1) D = slip_ld_piv(&P.piv[jn - 1]);
+        /* bring x[j] to its final value: history update to level jn-1 (:139-149) */
+        if (xj.len != 0 && xj.h < jn - 1) {
+            slip_u128 y = 0; int ys = 1;
+            if (slip_history_small(P, xj, xjv, D, xj.h, &y, &ys)) {
+                /* every thread derives the same value in registers; thread 0 stores it one step later */
+                dj = j; dy = y; dys = ys; dh = xj.h;
+                const int yb = slip_bits128(y), yl = (yb + 31) >> 5;
+                xj.len = ys < 0 ? -yl : yl; xj.bits = yb; xjv = (uint64_t) y;
+            } else {
+                slip_block_sync();
+                if (wave == 0) {
+                    if (slip_history_wave_out(&P, j, jn - 1, xj.h, b0, b1, b2)) { if (lane == 0) sv[SV_ERR] = 1; }
+                }
+                slip_block_sync();
+                xj = P.xrow[j];
+                xjv = slip_limb0(P.xd + (int64_t) j * P.xcap);
+            }
+        }
+        const int src_nz = xj.len != 0;
+        const int64_t m0 = slip_ld_i64(&P.Lp[jn]), m1 = slip_ld_i64(&P.Lp[jn + 1]);
+        const int src_small = slip_abs(xj.len) <= 2 && slip_abs(R.len) <= 2 && slip_abs(D.len) <= 2;
+        if (src_nz && tid == 0) {
+            c_src++;
+            c_read += 8ull * slip_limbs(R.len) + (jn >= 1 ? 8ull * slip_limbs(D.len) : 0ull);
+        }
+        uint32_t *wl = work + (step & 1) * 2 * SLIP_WORK_CAP;
+        volatile int32_t *wcnt = &sv[SV_CNT0 + step % 3];
+        /* stream L(:,jn): one entry per lane, SLIP_WORK_CAP entries per pass */
+        for (int64_t mb = m0; mb < m1; mb += SLIP_WORK_CAP) {
+            if (mb > m0) {
+                /* long column: drain the queue of the previous pass before refilling it */
+                slip_block_sync();
+                if (dj >= 0) {                      /* the wave path reads x[j] from memory */
+                    if (tid == 0) slip_store_small(P, dj, dy, dys, dh, tag);
+                    dj = -1;
+                    slip_block_sync();
+                }
+                const int nq2 = *wcnt;
+                slip_drain(P, lds, 1, j, jn, -1, m0, nq2, wl, b0, b1, b2);
+                if (tid == 0) *wcnt = 0;
+                slip_block_sync();
+            }
+            const int64_t me = mb + SLIP_WORK_CAP < m1 ? mb + SLIP_WORK_CAP : m1;
+            for (int64_t mm = mb; mm < me; mm += T) {
+                const int64_t m = mm + tid;
+                int queue = 0, qi = 0;                   /* this lane's update goes to the wave-item queue */
+                int fresh = 0, fi = 0;                   /* this lane discovered a row */
+                if (m < me) do {
+                const int i = slip_ld_i32(&P.Li[m]);
+                const SlipEnt le = slip_ld_ent(&P.Le[m]);
+                /* structural discovery (what the reference's DFS does): a row not yet tagged with this column */
+                SlipRow xi = P.xrow[i];
+                if (xi.tag != tag) {
+                    xi.len = 0; xi.h = -1; xi.bits = 0; xi.tag = tag; P.xrow[i] = xi;
+                    fresh = 1; fi = i;
+                }
+                if (!src_nz) break;
+                c_str++; c_read += 4 + 8ull * slip_limbs(le.len);
+                /* L(:,jn) holds its own pivot row j and rows that were non-pivotal when it was built: those sit at
+                 * positions above jn ever after (slip_REF_triangular_solve.c:160 `inew > jnew`) */
+                if (i == j || le.len == 0) break;
+                c_upd++;
+                c_mac += (unsigned long long) slip_limbs(le.len) * slip_limbs(xj.len) + (unsigned long long) slip_limbs(xi.len) * slip_limbs(R.len);
+                /* ---- one-limb operands: finish the update in this lane ---- */
+                int done = 0;
+                if (src_small && slip_abs(le.len) <= 2 && slip_abs(xi.len) <= 2) {
+                    const int lx = xi.len != 0, has_d = jn >= 1;
+                    const int hist = lx && has_d && xi.h < jn - 1, hdiv = hist && xi.h > -1;
+                    SlipPiv H = slip_piv_none();
+                    if (hdiv) H = slip_ld_piv(&P.piv[xi.h]);
+                    const int bxp = !lx ? 0 : (!hist ? xi.bits : (hdiv ? xi.bits + D.bits - H.bits + 1 : xi.bits + D.bits));
+                    const int b1b = lx ? bxp + R.bits : 0, b2b = le.bits + xj.bits;
+                    const int bnum = (b1b > b2b ? b1b : b2b) + 1;
+                    if (bnum <= 126 && (!hdiv || slip_abs(H.len) <= 2)) {
+                        slip_u128 y = 0; int s1 = slip_sgn(xi.len) * slip_sgn(R.len);
+                        if (lx) {
+                            y = (slip_u128) slip_limb0(P.xd + (int64_t) i * P.xcap);
+                            if (hist) { y *= D.lo; s1 *= slip_sgn(D.len); }
+                            if (hdiv) { y = slip_divexact128(y, H.lo, H.ctz, H.inv64); s1 *= slip_sgn(H.len); }
+                            y *= R.lo;
+                        }
+                        const slip_u128 p2 = (slip_u128) slip_limb0_s((const dig_t *)(P.Llimbs + le.off)) * xjv;
+                        const int s2 = slip_sgn(le.len) * slip_sgn(xj.len);
+                        slip_u128 mag; int sT;
+                        if (!lx) { mag = p2; sT = -s2; }
+                        else if (s1 == s2) { if (y >= p2) { mag = y - p2; sT = s1; } else { mag = p2 - y; sT = -s1; } }
+                        else { mag = y + p2; sT = s1; }
+                        if (has_d) { mag = slip_divexact128(mag, D.lo, D.ctz, D.inv64); sT *= slip_sgn(D.len); }
+                        slip_store_small(P, i, mag, sT, jn, tag);
+                        done = 1;
+                    }
+                }
+                if (!done) { queue = 1; qi = i; }
+                } while (0);
+                /* new rows join the row list; a row that is pivotal below the frontier becomes a later source */
+                slip_rlist_push(P, sv, fresh, fi);
+                if (fresh) {
+                    const int pos = slip_ld_i32(&P.pinv[fi]);
+                    if (pos < Fl) slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
+                }
+                /* queue slots per wave: one LDS atomic per wave instead of one per update on the same counter */
+                const uint64_t qm = slip_ballot(queue);
+                int qbase = 0;
+                if (lane == 0 && qm) qbase = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(qm));
+                qbase = (int) slip_shfl_u32((uint32_t) qbase, 0);
+                if (queue) {
+                    const int at = qbase + slip_popc64(qm & ((1ull << lane) - 1ull));
+                    wl[2 * at] = (uint32_t)(m - m0); wl[2 * at + 1] = (uint32_t) qi;
+                }
+            }
+        }
+        pj = j; pjn = jn;
+    }
+    return 0;
+}
+
+/* bitmap -> pattern: positions in ascending order (what slip_sort_xi.c produces) in LDS (or P.pat when long),
+ * the rows behind them next to it; *nU_out = how many of them are below k.  Called by all threads; ends before a barrier. */
+SLIP_DEV void slip_pattern(const SlipParams &P, uint32_t *lds, const uint32_t *bm, int k, int *npat_out, int *nU_out)
+{
+    const int tid = slip_tid(), T = slip_nthreads();
+    uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
+    const int nwords = P.bm_words;
+    const int per = (nwords + T - 1) / T;
+    int w0 = tid * per, w1 = w0 + per;
+    if (w0 > nwords) w0 = nwords;
+    if (w1 > nwords) w1 = nwords;
+    uint64_t cntA = 0, cntU = 0;
+    for (int w = w0; w < w1; w++) {
+        const uint32_t word = bm[w];
+        uint32_t below;
+        if ((w + 1) * 32 <= k) below = word;
+        else if (w * 32 >= k) below = 0;
+        else below = word & ((1u << (k - w * 32)) - 1u);
+        cntA += (uint64_t) slip_popc32(word); cntU += (uint64_t) slip_popc32(below);
+    }
+    uint32_t exA, exU, totA, totU_;              /* at most n < 2^31 set bits */
+    slip_block_scan2_small((uint32_t) cntA, (uint32_t) cntU, scan_tmp, &exA, &exU, &totA, &totU_);
+    {
+        /* short patterns never leave the CU (the readers pick the same place by npat) */
+        int o = (int) exA;
+        int32_t *patl = (int32_t *)(lds + SLIP_LDS_PAT);
+        const bool in_lds = totA <= SLIP_PAT_CAP;
+        for (int w = w0; w < w1; w++) {
+            uint32_t word = bm[w];
+            while (word) {
+                int b = slip_ctz32(word); word &= word - 1;
+                if (in_lds) patl[o++] = w * 32 + b; else P.pat[o++] = w * 32 + b;
+            }
+        }
+    }
+    /* the rows behind the positions, gathered once for the phases that follow (one parallel round of loads) */
+    if (totA <= SLIP_PAT_CAP) {
+        int32_t *patl = (int32_t *)(lds + SLIP_LDS_PAT), *rowl = (int32_t *)(lds + SLIP_LDS_ROWS);
+        slip_block_sync();
+        for (int t = tid; t < (int) totA; t += T) rowl[t] = slip_ld_i32(&P.row_perm[patl[t]]);
+    }
+    *npat_out = (int) totA; *nU_out = (int) totU_;
+}
+
+/* copy `len` digits (padded to whole limbs) from a private x row or the L slab to the L slab, write-through;
+ * returns (wave-uniform) the number of trailing zero bits of the value; one wavefront */
+SLIP_DEV int slip_publish_digits(dig_t *dst, const dig_t *src, int src_shared, int len)
+{
+    const int lane = slip_lane();
+    const int lw = (len + 1) & ~1;
+    int ctz = -1;
+    for (int base = 0; base < lw; base += SLIP_WAVE) {
+        const int c = base + lane;
+        uint32_t v = 0;
+        if (c < len) v = src_shared ? slip_ld_u32(src + c) : src[c];
+        if (c < lw && (!src_shared || dst != src)) slip_st_u32(dst + c, v);
+        if (ctz < 0) {
+            const uint64_t nz = slip_ballot(v != 0);
+            if (nz) { const int t = slip_ctz64(nz); ctz = 32 * (base + t) + slip_ctz32(slip_shfl_u32(v, t)); }
+        }
+    }
+    return ctz < 0 ? 0 : ctz;
+}
+
+/* ------------------------------------------------------------------ */
+/* one column; returns a SLIPDEV_* status (0 = committed), SLIPDEV_ABORTED when the column must be dropped */
+/* ------------------------------------------------------------------ */
+/* FAST: bitmap and wave scratch both in LDS (addresses provably LDS, ds_* instructions);
+ * otherwise the generic build picks either place at run time (flat addressing). */
+template <bool FAST>
+SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, const int tag, uint32_t *lds,
+                            unsigned long long *acc)
+{
+    const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
+    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
+    const int col = P.q[k];
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    volatile int64_t *sv64 = (volatile int64_t *)(lds + SLIP_LDS_VARS);
+    uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
+    uint32_t *work = lds + SLIP_LDS_WORK;
+    uint32_t *bm = BM_LDS ? lds + SLIP_LDS_BITMAP : P.gbitmap;
+    const int wcap = P.wcap;
+    dig_t *b0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
+                        : P.gscratch + (int64_t) wave * 3 * wcap;
+    dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
+    unsigned long long c_read = 0, c_upd = 0, c_src = 0, c_str = 0, c_mac = 0;
+    SLIP_STAMP_INIT();
+
+    /* ---- phase 0: clear the pattern bitmap, take a snapshot of the commit frontier ---- */
+    for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
+    if (tid == 0) {
+        sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv[SV_NROWS] = 0;
+        sv64[SV_LALLOC / 2] = 0; sv64[SV_LEXACT / 2] = 0;
+        /* the ready frontier first: it never passes the commit frontier, also not between the two loads */
+        sv[SV_F2] = slip_ld_i32(&st->F2);
+        int F = slip_ld_i32(&st->F);
+        sv[SV_F] = F < k ? F : k;
+    }
+    slip_block_sync();
+    const int F0 = sv[SV_F];
+
+    /* ---- phase 1: scatter A(:,col) into x (slip_REF_triangular_solve.c:105-119) ---- */
+    for (int64_t p0 = P.Ap[col]; p0 < P.Ap[col + 1]; p0 += T) {
+        const int64_t p = p0 + tid;
+        const int have = p < P.Ap[col + 1];
+        int row = 0;
+        if (have) {
+            row = P.Ai[p];
+            const int pos = slip_ld_i32(&P.pinv[row]);
+            if (pos < F0) slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));     /* pivotal below the frontier: a source */
+            const int32_t al = P.Alen[p];
+            const int la = slip_abs(al);
+            const dig_t *src = (const dig_t *)(P.Alimbs + P.Aoff[p]);
+            dig_t *X = P.xd + (int64_t) row * P.xcap;
+            SlipRow r; r.len = al; r.h = -1; r.tag = tag; r.bits = 0;
+            if (la > P.xcap) sv[SV_ERR] = 1;
+            else {
+                const int lw = (la + 1) & ~1;
+                for (int c = 0; c < lw; c++) X[c] = c < la ? src[c] : 0u;
+                r.bits = la ? 32 * la - slip_clz32(src[la - 1]) : 0;
+            }
+            P.xrow[row] = r;
+            c_read += 4 + 8 * (unsigned long long)((la + 1) >> 1);
+        }
+        slip_rlist_push(P, sv, have, row);
+    }
+    slip_block_sync();
+    if (sv[SV_ERR]) return SLIPDEV_GROW_X;
+    SLIP_STAMP(0);
+
+    /* ---- phase 2: ascending sweep over the pivotal part of the pattern, ahead of the frontier ---- */
+    if (slip_sweep<FAST, true>(P, st, k, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac)) return SLIPDEV_ABORTED;
+    slip_block_sync();
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+    SLIP_STAMP(1);
+    /* from here on F == k: columns 0..k-1 are committed, pinv / row_perm are those of the reference at column k */
+
+    /* ---- phase 3: the rows that are still non-pivotal take their (now final) positions; reading the
+     *      bitmap in order = the sorted pattern (slip_sort_xi.c) ---- */
+    {
+        const int nrows = sv[SV_NROWS];
+        for (int t = tid; t < nrows; t += T) {
+            const int r = P.rlist[t];
+            const int pos = slip_ld_i32(&P.pinv[r]);
+            slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
+        }
+        if (tid == 0) {
+            sv64[SV_LNZ / 2] = slip_ld_i64(&P.Lp[k]); sv64[SV_LNL / 2] = slip_ld_i64(&P.Lo[k]);
+            sv64[SV_UNZ / 2] = slip_ld_i64(&P.Up[k]); sv64[SV_UNL / 2] = slip_ld_i64(&P.Uo[k]);
+        }
+        slip_block_sync();
+    }
+    const int pc_col = slip_ld_i32(&P.pinv[col]);       /* position of the "diagonal" row: fixed until this column's swap */
+    int npat_, nU_;
+    slip_pattern(P, lds, bm, k, &npat_, &nU_);
+    const int npat = npat_, nU = nU_, nL = npat - nU;
+    const int32_t *patl = (const int32_t *)(lds + SLIP_LDS_PAT);
+    auto pat_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? patl[t] : P.pat[t]; };
+    const int32_t *rowl = (const int32_t *)(lds + SLIP_LDS_ROWS);
+    uint32_t *diroff = lds + SLIP_LDS_DIROFF;
+    auto row_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? rowl[t] : slip_ld_i32(&P.row_perm[P.pat[t]]); };
+    slip_block_sync();
+    if (npat != sv[SV_NROWS]) return SLIPDEV_INTERNAL;  /* every discovered row has exactly one position */
+    SLIP_STAMP(2);
+
+    /* ---- phase 4: history update of the non-pivotal rows to level k-1 (:248-257) ---- */
+    /* one-limb rows finished by a lane enter the column table (and the key list of the pivot search) from that lane's
+     * registers (diroff[] = 0x7FFFFFFF); for rows multiplied straight into the L slab diroff[] holds the slab offset;
+     * all-ones: neither */
+    const int prefill_ok = k >= 1 && npat <= SLIP_PAT_CAP;
+    uint32_t *ctab = lds + SLIP_LDS_TAB, *ckeys = lds + SLIP_LDS_KEYS;
+    if (k >= 1) {
+        volatile int32_t *wcnt = &sv[SV_CNT0], *wcnt2 = &sv[SV_CNT0 + 1];
+        if (tid == 0) { *wcnt = 0; *wcnt2 = 0; }
+        uint32_t *wl2 = work + SLIP_WORK_CAP;              /* 5-word records, SLIP_WORK_CAP of them */
+        /* rho[k-1] is the multiplier of every row: stage its digits once (LDS when it fits) */
+        const SlipPiv M = slip_ld_piv(&P.piv[k - 1]);
+        const int lm = slip_abs(M.len);
+        const dig_t *Mg = slip_piv_digits(P, M);
+        dig_t *Ms = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + nw * 3 * wcap : (dig_t *) 0;
+        const dig_t *Md = Mg; int md_shared = 1;
+        if (SCR_LDS && lm <= wcap) { for (int c = tid; c < lm; c += T) Ms[c] = slip_ld_u32(Mg + c); Md = Ms; md_shared = 0; }
+        slip_block_sync();
+        SLIP_STAMP(8);
+        uint32_t *wl = work;
+        const unsigned long long slot = (unsigned long long)((lm + 3) >> 1);
+        for (int t0 = 0; t0 < nL; t0 += SLIP_WORK_CAP) {
+            const int te = t0 + SLIP_WORK_CAP < nL ? t0 + SLIP_WORK_CAP : nL;
+            const unsigned long long chunk_base = (unsigned long long) sv64[SV_LALLOC / 2];
+            for (int tb = t0; tb < te; tb += T) {
+                /* every lane classifies its row; list slots are then handed out per WAVE (one LDS atomic per wave and list
+                 * instead of one per row on the same counter) */
+                const int t = tb + tid;
+                int cls = 0, r = 0;                          /* 1: one limb times the long pivot, 2: wave item (division) */
+                SlipRow xr; xr.len = 0; xr.h = 0; xr.bits = 0; xr.tag = 0;
+                uint64_t xv = 0;
+                if (t < te) {
+                r = row_at(nU + t);
+                xr = P.xrow[r];
+                if (npat <= SLIP_PAT_CAP) diroff[nU + t] = 0xFFFFFFFFu;
+                }
+                if (t < te && !(xr.len == 0 || xr.h >= k - 1)) {
+                int done = 0;
+                if (slip_abs(xr.len) <= 2) {
+                    xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                    slip_u128 y = 0; int ys = 1;
+                    if (slip_history_small(P, xr, xv, M, xr.h, &y, &ys)) {
+                        slip_store_small(P, r, y, ys, xr.h, tag);
+                        if (npat <= SLIP_PAT_CAP) {          /* the lane has the value: table entry and pivot key from registers */
+                            const int yb = slip_bits128(y), yl = (yb + 31) >> 5, pidx = nU + t;
+                            ctab[0 * SLIP_TAB_CAP + pidx] = (uint32_t) r; ctab[1 * SLIP_TAB_CAP + pidx] = (uint32_t)(ys < 0 ? -yl : yl);
+                            ctab[2 * SLIP_TAB_CAP + pidx] = (uint32_t) yb; ctab[3 * SLIP_TAB_CAP + pidx] = 0u;
+                            const uint64_t top = yb ? (uint64_t)((y << (128 - yb)) >> 64) : 0ull;
+                            ckeys[2 * pidx] = (uint32_t) top; ckeys[2 * pidx + 1] = (uint32_t)(top >> 32);
+                            diroff[pidx] = 0x7FFFFFFFu;      /* entered, value in its x row */
+                        }
+                        done = 1;
+                    } else if (xr.h < 0 && lm + 2 <= P.xcap && lm + 2 <= 256) {
+                        /* one limb times a long pivot, no division: wave path with the pivot in registers */
+                        /* every such row gets a slot of (lm+3)/2 limbs in the L slab (the product has at most lm+2 digits) */
+                        cls = 1;
+                        done = 1;
+                    } else if (xr.h < 0 && lm + 2 <= P.xcap) {
+                        /* beyond 256 digits: this lane walks the pivot's digits */
+                        dig_t *X = P.xd + (int64_t) r * P.xcap;
+                        const uint64_t a0 = xv & 0xFFFFFFFFu, a1 = xv >> 32;
+                        uint64_t carry = 0;              /* < 2^64 */
+                        for (int c = 0; c < lm; c++) {
+                            const uint64_t d = md_shared ? slip_ld_u32(Md + c) : Md[c];
+                            const uint64_t lo = a0 * d + (carry & 0xFFFFFFFFu);          /* < 2^64 */
+                            X[c] = (uint32_t) lo;
+                            carry = a1 * d + (carry >> 32) + (lo >> 32);                 /* < 2^64 */
+                        }
+                        int len = lm;
+                        if (carry) { X[len++] = (uint32_t) carry; if (carry >> 32) X[len++] = (uint32_t)(carry >> 32); }
+                        if (len & 1) X[len] = 0;
+                        SlipRow nr; nr.len = (slip_sgn(xr.len) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = xr.h; nr.tag = tag;
+                        nr.bits = 32 * len - slip_clz32(X[len - 1]);
+                        P.xrow[r] = nr;
+                        done = 1;
+                    }
+                }
+                if (!done) cls = 2;
+                }
+                const uint64_t m1 = slip_ballot(cls == 1), m2 = slip_ballot(cls == 2);
+                int base1 = 0, base2 = 0;
+                if (lane == 0) {
+                    if (m1) base1 = slip_atomic_add_i32((int32_t *) wcnt2, slip_popc64(m1));
+                    if (m2) base2 = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(m2));
+                }
+                base1 = (int) slip_shfl_u32((uint32_t) base1, 0); base2 = (int) slip_shfl_u32((uint32_t) base2, 0);
+                const uint64_t below = (1ull << lane) - 1ull;
+                if (cls == 1) {
+                    const int at = base1 + slip_popc64(m1 & below);
+                    wl2[5 * at] = (uint32_t) r; wl2[5 * at + 1] = (uint32_t) xv; wl2[5 * at + 2] = (uint32_t)(xv >> 32);
+                    wl2[5 * at + 3] = ((uint32_t)(nU + t) << 3) | (xr.len < 0 ? 4u : 0u) | (uint32_t) slip_abs(xr.len);
+                    wl2[5 * at + 4] = (uint32_t)(chunk_base + (unsigned long long) at * slot);
+                    if (npat <= SLIP_PAT_CAP) diroff[nU + t] = wl2[5 * at + 4];
+                } else if (cls == 2) {
+                    wl[base2 + slip_popc64(m2 & below)] = (uint32_t) r;
+                }
+            }
+            slip_block_sync();
+            SLIP_STAMP(9);
+            /* the slots handed out above must exist before anything is written into them */
+            const unsigned long long lalloc_now = chunk_base + (unsigned long long) *wcnt2 * slot;
+            if (sv64[SV_LNL / 2] + (int64_t) lalloc_now > P.Lcap_nl) return SLIPDEV_GROW_L;
+            const int nq = *wcnt;
+            const int n2 = *wcnt2;
+            const int64_t sb = sv64[SV_LNL / 2];
+            if (n2 > 0) {
+                const int e = slip_mul_rows_any(P, M, Md, md_shared, wl2, wave, nw, n2, sb, prefill_ok ? ctab : (uint32_t *) 0, ckeys, tag);
+                if (e && lane == 0) sv[SV_ERR] = 1;
+            }
+            slip_block_sync();
+            slip_drain(P, lds, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
+            SLIP_STAMP(10);
+            if (tid == 0) { *wcnt = 0; *wcnt2 = 0; sv64[SV_LALLOC / 2] = (int64_t) lalloc_now; }
+            slip_block_sync();
+        }
+    }
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+    SLIP_STAMP(3);
+
+    /* ---- phase 5: column-window cap, then the pivot search ---- */
+    /* column table in LDS (four arrays of SLIP_TAB_CAP words: row, signed length, bit length, flag/offset per pattern
+     * entry -- struct-of-arrays so that consecutive lanes hit consecutive banks): read once, used by
+     * the cap test, the pivot search, the offsets and the copy below */
+    uint32_t *tab = lds + SLIP_LDS_TAB;
+    const bool use_tab = npat <= SLIP_TAB_CAP;
+    const int64_t Lnl0 = sv64[SV_LNL / 2];              /* L slab cursor at the start of this column */
+    auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[0 * SLIP_TAB_CAP + t] : row_at(t); };
+    auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[1 * SLIP_TAB_CAP + t] : P.xrow[row_at(t)].len; };
+    auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[2 * SLIP_TAB_CAP + t] : P.xrow[row_at(t)].bits; };
+    /* where the digits of a row are: its x row (private), or (rows multiplied straight into L: h == -2) the slab (shared) */
+    auto row_direct = [&](int r) -> int { return P.xrow[r].h == -2; };
+    auto row_digits = [&](int r) -> const dig_t * {
+        const dig_t *X = P.xd + (int64_t) r * P.xcap;
+        return P.xrow[r].h == -2 ? (const dig_t *)(P.Llimbs + *(const int64_t *) X) : X;
+    };
+    auto ent_direct = [&](int t) -> int { return use_tab ? (int)(tab[3 * SLIP_TAB_CAP + t] >> 31) : row_direct(row_at(t)); };
+    auto ent_digits = [&](int t) -> const dig_t * {
+        if (use_tab) return (tab[3 * SLIP_TAB_CAP + t] >> 31) ? (const dig_t *)(P.Llimbs + Lnl0 + (int64_t)(tab[3 * SLIP_TAB_CAP + t] & 0x7FFFFFFFu))
+                                                  : P.xd + (int64_t) tab[0 * SLIP_TAB_CAP + t] * P.xcap;
+        return row_digits(row_at(t));
+    };
+    {
+        int mx = 0;
+        for (int t = tid; t < npat; t += T) {
+            if (prefill_ok && t >= nU && diroff[t] == 0x7FFFFFFFu) {     /* entered by the lane that produced the value */
+                const int l = slip_abs((int32_t) tab[1 * SLIP_TAB_CAP + t]);
+                if (l > mx) mx = l;
+                continue;
+            }
+            if (prefill_ok && t >= nU && diroff[t] != 0xFFFFFFFFu) {     /* entered by the wave that multiplied the row into the slab */
+                const int l = slip_abs((int32_t) tab[1 * SLIP_TAB_CAP + t]);
+                if (l > mx) mx = l;
+                continue;
+            }
+            const int r = row_at(t);
+            const SlipRow xr = P.xrow[r];
+            const int l = slip_abs(xr.len);
+            if (l > mx) mx = l;
+            if (use_tab) {
+                tab[0 * SLIP_TAB_CAP + t] = (uint32_t) r; tab[1 * SLIP_TAB_CAP + t] = (uint32_t) xr.len; tab[2 * SLIP_TAB_CAP + t] = (uint32_t) xr.bits;
+                tab[3 * SLIP_TAB_CAP + t] = xr.h == -2 ? (0x80000000u | (uint32_t)(*(const int64_t *)(P.xd + (int64_t) r * P.xcap) - Lnl0)) : 0u;
+            }
+        }
+        mx = slip_wave_max_i32(mx);
+        if (mx > 0 && lane == 0) slip_atomic_max_i32((int32_t *) &sv[SV_MAXDIG], mx);
+        slip_block_sync();
+    }
+    const int maxdig = sv[SV_MAXDIG];
+    if (P.limb_cap > 0 && ((maxdig + 1) >> 1) > P.limb_cap) return SLIPDEV_WINDOW_END;
+    SLIP_STAMP(12);                                       /* column table built */
+
+    /* kind of search: 0 smallest, 1 largest, 2 first nonzero (slip_get_pivot.c:58-155).
+     * Lanes order the candidates by (bit length, leading bits); the candidates that tie on
+     * that key are compared exactly, ties resolved towards the earlier pattern position. */
+    const int scheme = P.pivot_scheme;
+    const int kind = (scheme == 2) ? 2 : ((scheme == 4 || scheme == 5) ? 1 : 0);
+    int best = -1;
+    if (kind != 2 && maxdig < (1 << 18)) {
+        /* one pass: (bit length, leading 40 bits) packed into one key; the candidates that share the best key are
+         * compared exactly, ties towards the earlier pattern position (slip_get_smallest_pivot.c:79) */
+        auto key_of = [&](int t) -> uint64_t {
+            const int32_t xl = ent_len(nU + t);
+            if (xl == 0) return ~0ull;
+            const bool pre = prefill_ok && diroff[nU + t] != 0xFFFFFFFFu;
+            const uint64_t top = pre ? ((uint64_t) ckeys[2 * (nU + t)] | ((uint64_t) ckeys[2 * (nU + t) + 1] << 32))
+                                     : slip_top64(ent_digits(nU + t), slip_abs(xl), ent_direct(nU + t));
+            const uint64_t v = ((uint64_t) ent_bits(nU + t) << 40) | (top >> 24);
+            return kind == 0 ? v : ~v;
+        };
+        uint64_t mykey = ~0ull, k1 = ~0ull;
+        for (int t = tid; t < nL; t += T) { const uint64_t c = key_of(t); if (t == tid) mykey = c; if (c < k1) k1 = c; }
+        const uint64_t mk = slip_block_min_u64(k1, scan_tmp);
+        if (mk == ~0ull) return SLIPDEV_SINGULAR;
+        if (tid == 0) sv[SV_LISTN] = 0;
+        slip_block_sync();
+        for (int t = tid; t < nL; t += T) {
+            const uint64_t c = t == tid ? mykey : key_of(t);
+            if (c != mk) continue;
+            const int at = slip_atomic_add_i32((int32_t *) &sv[SV_LISTN], 1);
+            if (at < 2 * SLIP_WORK_CAP) work[at] = (uint32_t) t;
+        }
+        slip_block_sync();
+        const int nc = sv[SV_LISTN];
+        /* every wave performs the same reduction (wave-uniform, reads only) */
+        const int listed = nc <= 2 * SLIP_WORK_CAP;
+        const int kbits = (int)((kind == 0 ? mk : ~mk) >> 40);   /* at most 40 bits: equal keys are equal values */
+        for (int c = 0; c < (listed ? nc : nL); c++) {
+            const int t = listed ? (int) work[c] : c;
+            if (!listed && key_of(t) != mk) continue;
+            if (best < 0) { best = t; continue; }
+            int cmp = 0;
+            if (kbits > 40)      /* equal keys have equal bit lengths, hence equal digit counts */
+                cmp = slip_cmp_mag(ent_digits(nU + best), ent_direct(nU + best), ent_digits(nU + t), ent_direct(nU + t), slip_abs(ent_len(nU + t)));
+            if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && t < best)) best = t;
+        }
+        slip_block_sync();
+    } else {
+        uint64_t k1 = ~0ull;                                     /* (key, t) packed: smaller is better */
+        for (int t = tid; t < nL; t += T) {
+            if (ent_len(nU + t) == 0) continue;
+            const int bits = ent_bits(nU + t);
+            const uint64_t key = kind == 2 ? 0 : (kind == 0 ? (uint64_t) bits : (uint64_t)(0x7FFFFFFF - bits));
+            const uint64_t c = (key << 32) | (uint32_t) t;
+            if (c < k1) k1 = c;
+        }
+        k1 = slip_block_min_u64(k1, scan_tmp);
+        if (k1 == ~0ull) return SLIPDEV_SINGULAR;
+        if (kind == 2) best = (int)(k1 & 0xFFFFFFFFu);
+        else {
+            const uint32_t bkey = (uint32_t)(k1 >> 32);
+            const int bbits = kind == 0 ? (int) bkey : 0x7FFFFFFF - (int) bkey;
+            /* exact comparison among the candidates of the winning bit-length class, in pattern order */
+            for (int t = 0; t < nL; t++) {
+                const int32_t xl = ent_len(nU + t);
+                if (xl == 0 || ent_bits(nU + t) != bbits) continue;
+                if (best < 0) { best = t; continue; }
+                const int cmp = slip_cmp_mag(ent_digits(nU + best), ent_direct(nU + best), ent_digits(nU + t), ent_direct(nU + t), slip_abs(xl));
+                if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0)) best = t;
+            }
+            slip_block_sync();
+        }
+    }
+    SLIP_STAMP(13);                                       /* smallest / largest candidate known */
+    int pivrow = ent_row(nU + best);
+    /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146) */
+    if (scheme == 1 || scheme == 3 || scheme == 4) {
+        const int pc = pc_col;
+        const int diag_ok = pc >= k && ((bm[pc >> 5] >> (pc & 31)) & 1u) && P.xrow[col].tag == tag && P.xrow[col].len != 0;
+        if (diag_ok && pivrow != col) {
+            int take = 0, err = 0;
+            if (scheme == 1) take = 1;
+            else if (P.tol_mode == 0) take = 1;
+            else {
+                const int lp_ = slip_abs(P.xrow[pivrow].len), lc_ = slip_abs(P.xrow[col].len);
+                /* tol_m has exactly 53 bits, so tol_m*|den| has 52 or 53 bits more than |den|: most columns
+                 * are decided by the bit lengths alone */
+                const int te0 = P.tol_e;
+                const int bnum_ = (scheme == 3 ? P.xrow[pivrow].bits : P.xrow[col].bits) + (te0 < 0 ? -te0 : 0);
+                const int bden_ = (scheme == 3 ? P.xrow[col].bits : P.xrow[pivrow].bits) + (te0 > 0 ? te0 : 0);
+                if (bnum_ < 52 + bden_) take = 0;
+                else if (bnum_ > 53 + bden_) take = 1;
+                else {
+                    /* exact comparison.  Every wave runs it redundantly in its own scratch.  A row that lives in the L
+                     * slab is shared data: its digits are staged (sc1 loads) into scratch the comparison does not need
+                     * at that point -- the denominator into b1 (free until the last step, when the denominator has
+                     * been consumed), the numerator behind the product in b2. */
+                    const int rn = scheme == 3 ? pivrow : col, rd = scheme == 3 ? col : pivrow;   /* |small|/|diag| or |diag|/|large| >= tol */
+                    const int ln = scheme == 3 ? lp_ : lc_, ldn = scheme == 3 ? lc_ : lp_;
+                    const dig_t *num = P.xd + (int64_t) rn * P.xcap, *den = P.xd + (int64_t) rd * P.xcap;
+                    if (ldn + 2 > wcap) err = 1;
+                    if (!err && row_direct(rd)) { slip_stage_shared(b1, row_digits(rd), ldn); den = b1; }
+                    if (!err && row_direct(rn)) {
+                        if (ldn + 4 + ln > wcap) err = 1;
+                        else { slip_stage_shared(b2 + ldn + 4, row_digits(rn), ln); num = b2 + ldn + 4; }
+                    }
+                    if (!err) {
+                        const int tk = slip_tol_compare_out(P.tol_m, P.tol_e, num, ln, den, ldn, b0, b1, b2, wcap);
+                        if (tk < 0) err = 1; else take = tk;
+                    }
+                }
+            }
+            if (err) return SLIPDEV_GROW_X;
+            if (take) pivrow = col;
+        }
+    }
+    const int pivpos = pivrow == col ? pc_col : pat_at(nU + best);   /* pre-swap position (the pattern holds positions), >= k */
+    SLIP_STAMP(4);
+
+    /* ---- phase 6: append U(:,k) and L(:,k) (SLIP_LU_factorize.c:226-263) ---- */
+    /* U(:,k): pattern rows below k in order, then the pivot.  L(:,k): rows at or above k in order. */
+    const int nUe = nU + 1, nE = nUe + nL;
+    const int64_t Lnz = sv64[SV_LNZ / 2], Lnl = sv64[SV_LNL / 2], Unz = sv64[SV_UNZ / 2], Unl = sv64[SV_UNL / 2];
+    uint64_t baseU = 0, baseL = 0;
+    /* pattern index of output entry e: U part, then the pivot (L position `pividx`), then the L part */
+    int pividx = nU + best;
+    if (pivrow != ent_row(nU + best)) {               /* the diagonal was preferred: find it in the L part */
+        if (tid == 0) sv[SV_TMP] = -1;
+        slip_block_sync();
+        for (int t = tid; t < nL; t += T) if (ent_row(nU + t) == pivrow) sv[SV_TMP] = nU + t;
+        slip_block_sync();
+        pividx = sv[SV_TMP];
+    }
+    /* rows multiplied straight into the L slab (phase 4) already own the first `lalloc` limbs behind Lnl;
+     * the other L rows are copied behind them */
+    const uint64_t lalloc = (uint64_t) sv64[SV_LALLOC / 2];
+    uint64_t dirL = 0;                                   /* exact limbs of the direct rows (channel packed with U) */
+    for (int e0 = 0; e0 < nE; e0 += T) {
+        const int e = e0 + tid;
+        int r = -1, pt = 0, direct = 0; uint64_t lu = 0, ll = 0; int32_t xl = 0; int xb = 0; int64_t doff = 0;
+        if (e < nE) {
+            pt = e < nU ? e : (e == nU ? pividx : e - 1);
+            r = ent_row(pt); xl = ent_len(pt); xb = ent_bits(pt);
+            if (e < nUe) lu = (uint64_t) slip_limbs(xl);
+            else {
+                if (use_tab) { direct = (int)(tab[3 * SLIP_TAB_CAP + pt] >> 31); doff = Lnl + (int64_t)(tab[3 * SLIP_TAB_CAP + pt] & 0x7FFFFFFFu); }
+                else if (P.xrow[r].h == -2) { direct = 1; doff = *(const int64_t *)(P.xd + (int64_t) r * P.xcap); }
+                if (!direct) ll = (uint64_t) slip_limbs(xl);
+                else lu = (uint64_t) slip_limbs(xl) << 32;             /* summed in the high half of the U channel */
+            }
+        }
+        uint64_t eu, el, tu, tl;
+        slip_block_scan2(lu, ll, scan_tmp, &eu, &el, &tu, &tl);
+        if (e < nE) {
+            /* capacity is verified before anything is committed; these records are provisional (nobody reads beyond the
+             * published column pointers) */
+            if (e < nUe) {
+                const int64_t at = Unz + e;
+                if (at < P.Ucap_nz) { P.Ui[at] = r; SlipEnt en; en.off = Unl + (int64_t)(baseU + (eu & 0xFFFFFFFFull)); en.len = xl; en.bits = xb; P.Ue[at] = en; }
+                if (use_tab) work[e] = (uint32_t)(baseU + (eu & 0xFFFFFFFFull));     /* copy destination inside the U slab */
+            } else {
+                const int64_t at = Lnz + (e - nUe);
+                const int64_t off = direct ? doff : Lnl + (int64_t)(lalloc + baseL + el);
+                if (at < P.Lcap_nz) { slip_st_i32(&P.Li[at], r); SlipEnt en; en.len = xl; en.bits = xb; en.off = off; slip_st_ent(&P.Le[at], en); }
+                if (use_tab && !direct) tab[3 * SLIP_TAB_CAP + pt] = (uint32_t)(off - Lnl);     /* copy destination, flag bit clear */
+            }
+        }
+        baseU += tu & 0xFFFFFFFFull; dirL += tu >> 32; baseL += tl;
+    }
+    const uint64_t totU = baseU, totL = lalloc + baseL;         /* limbs of slab consumed by this column */
+    const uint64_t totLexact = baseL + dirL;
+    if (Unz + nUe > P.Ucap_nz || Unl + (int64_t) totU > P.Ucap_nl) return SLIPDEV_GROW_U;
+    if (Lnz + nL > P.Lcap_nz || Lnl + (int64_t) totL > P.Lcap_nl) return SLIPDEV_GROW_L;
+    slip_vm_drain();                                     /* the direct rows' and the records' write-through stores have left */
+    slip_block_sync();
+    SLIP_STAMP(5);
+
+    /* ---- stage 1: publish the pivot.  Wave 0 moves the pivot's digits to their place in the L slab (if they are
+     *      not there yet), builds the pivot record, swaps the permutation and publishes the column pointers; then
+     *      the frontier moves and the next column may commit while this one still writes its bulk. ---- */
+    if (wave == 0) {
+        const int found = pividx - nU;                   /* position of the pivot inside L(:,k) */
+        const int32_t plen = ent_len(pividx);
+        const int pbits = ent_bits(pividx);
+        const int lp_ = slip_abs(plen);
+        int pdirect; int64_t poff;
+        if (use_tab) { pdirect = (int)(tab[3 * SLIP_TAB_CAP + pividx] >> 31); poff = Lnl + (int64_t)(tab[3 * SLIP_TAB_CAP + pividx] & 0x7FFFFFFFu); }
+        else { const SlipEnt pe = slip_ld_ent(&P.Le[Lnz + found]); pdirect = row_direct(pivrow); poff = pe.off; }
+        dig_t *dst = (dig_t *)(P.Llimbs + poff);
+        const dig_t *src = pdirect ? (const dig_t *) dst : P.xd + (int64_t) pivrow * P.xcap;
+        const int z = slip_publish_digits(dst, src, pdirect, lp_);
+        const uint64_t lo64 = pdirect ? slip_ld_u64((const uint64_t *) dst) : *(const uint64_t *) src;
+        slip_vm_drain();
+        if (lane == 0) {
+            SlipPiv pr; pr.off = poff; pr.len = plen; pr.bits = pbits; pr.ctz = z; pr.invlen = 0;
+            pr.lo = lo64; pr.inv64 = 0; pr.pad = 0;
+            if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
+            slip_st_piv(&P.piv[k], pr);
+            const int intermed = pivpos, intermed2 = slip_ld_i32(&P.row_perm[k]);
+            slip_st_i32(&P.row_perm[k], pivrow); slip_st_i32(&P.row_perm[intermed], intermed2);
+            slip_st_i32(&P.pinv[pivrow], k); slip_st_i32(&P.pinv[intermed2], intermed);
+            slip_st_i64(&P.Up[k + 1], Unz + nUe); slip_st_i64(&P.Lp[k + 1], Lnz + nL);
+            slip_st_i64(&P.Uo[k + 1], Unl + (int64_t) totU); slip_st_i64(&P.Lo[k + 1], Lnl + (int64_t) totL);
+            slip_vm_drain();
+            slip_st_i32(&st->F, k + 1);
+        }
+    }
+    SLIP_STAMP(6);
+
+    /* ---- stage 2: the limbs.  One wave per entry, coalesced; x rows are stored padded to whole limbs.  Rows that
+     *      already live in the L slab are not copied.  L is shared (write-through), U is only read by later launches. ---- */
+    /* the lanes of a wave look at its entries side by side and only the entries that really need a copy (U entries,
+     * L rows that are not already in the slab) are then walked one after the other */
+    for (int base = wave; base < nE; base += nw * SLIP_WAVE) {
+    uint64_t todo_e;
+    {
+        const int el = base + nw * lane;
+        int need = 0;
+        if (el < nE) need = (use_tab && el >= nUe) ? !(tab[3 * SLIP_TAB_CAP + (el - 1)] >> 31) : 1;
+        todo_e = slip_ballot(need);
+    }
+    while (todo_e) {
+        const int e = base + nw * slip_ctz64(todo_e);
+        todo_e &= todo_e - 1;
+        const int isU = e < nUe;
+        const dig_t *srcx; dig_t *dst; int32_t xl; int src_shared = 0;
+        if (use_tab && isU) {
+            /* U(:,k): pivotal rows live in x; the pivot (last) may have been multiplied straight into the L slab */
+            const int pt = e < nU ? e : pividx;
+            xl = (int32_t) tab[1 * SLIP_TAB_CAP + pt];
+            src_shared = (int)(tab[3 * SLIP_TAB_CAP + pt] >> 31);
+            /* (the pivot is read where the column produced it, not from the L copy wave 0 may still be writing) */
+            srcx = src_shared ? (const dig_t *)(P.Llimbs + Lnl + (int64_t)(tab[3 * SLIP_TAB_CAP + pt] & 0x7FFFFFFFu))
+                              : P.xd + (int64_t) tab[0 * SLIP_TAB_CAP + pt] * P.xcap;
+            dst = (dig_t *)(P.Ulimbs + Unl + (int64_t) work[e]);
+        } else if (use_tab) {
+            const int pt = e - 1;
+            if (tab[3 * SLIP_TAB_CAP + pt] >> 31) continue;                 /* multiplied straight into the slab */
+            if (pt == pividx) continue;                                    /* copied at stage 1 */
+            xl = (int32_t) tab[1 * SLIP_TAB_CAP + pt];
+            srcx = P.xd + (int64_t) tab[0 * SLIP_TAB_CAP + pt] * P.xcap;
+            dst = (dig_t *)(P.Llimbs + Lnl + (int64_t) tab[3 * SLIP_TAB_CAP + pt]);
+        } else {
+            const int64_t at = isU ? Unz + e : Lnz + (e - nUe);
+            const int r = isU ? P.Ui[at] : slip_ld_i32(&P.Li[at]);
+            const SlipEnt en = isU ? P.Ue[at] : slip_ld_ent(&P.Le[at]);
+            xl = en.len;
+            src_shared = row_direct(r);
+            srcx = row_digits(r);
+            dst = isU ? (dig_t *)(P.Ulimbs + en.off) : (dig_t *)(P.Llimbs + en.off);
+            if (!isU && (src_shared || r == pivrow)) continue;              /* in the slab already / copied at stage 1 */
+        }
+        const int lw = (slip_abs(xl) + 1) & ~1;
+        if (isU) { for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = src_shared ? slip_ld_u32(srcx + c) : srcx[c]; }
+        else     { for (int c = lane; c < lw; c += SLIP_WAVE) slip_st_u32(dst + c, srcx[c]); }
+    }
+    }
+    slip_vm_drain();
+    slip_block_sync();
+    if (tid == 0) {
+        slip_agent_add_i32(&P.Lready[k], 1);             /* returning atomic: performed before the advance below reads the flags */
+        slip_advance_ready(P, st);
+        const int32_t plen = ent_len(pividx);
+        slip_agent_add_u64(&st->c_write, 4ull * (unsigned long long) nE + 8ull * (totU + totLexact) + 8ull * slip_limbs(plen));
+        slip_agent_add_u64((unsigned long long *) &st->Lnl_exact, totLexact);
+        slip_agent_add_u64((unsigned long long *) &st->Unl_exact, totU);
+        slip_agent_max_u64(&st->c_maxdig, (unsigned long long) maxdig);
+    }
+    acc[0] += c_read; acc[1] += c_upd; acc[2] += c_src; acc[3] += c_str; acc[4] += c_mac;
+    SLIP_STAMP(7);
+    SLIP_STAMP_FLUSH(st);
+    slip_block_sync();
+    return SLIPDEV_OK;
+}
+
+/* the kernel body of a column worker: draw columns from the ticket counter until none is left */
+template <bool FAST>
+SLIP_DEV void slip_factor_worker(const SlipParams &P, SlipState *st, uint32_t *lds)
+{
+    const int tid = slip_tid();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
+    unsigned long long acc[5] = {0, 0, 0, 0, 0};
+    for (;;) {
+        slip_block_sync();
+        if (tid == 0) {
+            const int t = slip_agent_add_i32(&st->ticket, 1);
+            int k = P.k0 + (t - P.t0);
+            /* a column beyond the one that stopped the factorisation can never commit */
+            if (k < P.k_stop && (slip_ld_i64(&st->stop) >> 8) < (int64_t) k) k = P.k_stop;
+            sv[SV_K] = k; sv[SV_TAG] = t + 1;
+        }
+        slip_block_sync();
+        const int k = sv[SV_K], tag = sv[SV_TAG];
+        if (k >= P.k_stop) break;
+        const int status = slip_do_column<FAST>(P, st, k, tag, lds, acc);
+        if (status == SLIPDEV_OK) continue;
+        if (status != SLIPDEV_ABORTED && tid == 0) slip_raise_stop(st, status == SLIPDEV_INTERNAL ? 0 : k, status);
+        break;
+    }
+    slip_block_sync();
+    /* per-thread counters of the committed columns -> totals */
+    unsigned long long v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    slip_block_sum4(v, scan_tmp);
+    unsigned long long w[4] = {acc[4], 0, 0, 0};
+    slip_block_sum4(w, scan_tmp);
+    if (tid == 0) {
+        if (v[0]) slip_agent_add_u64(&st->c_read, v[0]);
+        if (v[1]) slip_agent_add_u64(&st->c_upd, v[1]);
+        if (v[2]) slip_agent_add_u64(&st->c_src, v[2]);
+        if (v[3]) slip_agent_add_u64(&st->c_streamed, v[3]);
+        if (w[0]) slip_agent_add_u64(&st->c_macs, w[0]);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* REF forward / back substitution for one right-hand side             */
+/* ------------------------------------------------------------------ */
+template <bool FAST>
+SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveArgs &A, const int c, const int tag, uint32_t *lds)
+{
+    const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave();
+    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
+    const int n = P.n;
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
+    uint32_t *work = lds + SLIP_LDS_WORK;
+    uint32_t *bm = BM_LDS ? lds + SLIP_LDS_BITMAP : P.gbitmap;
+    const int wcap = P.wcap;
+    dig_t *b0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
+                        : P.gscratch + (int64_t) wave * 3 * wcap;
+    dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
+    unsigned long long c_read = 0, c_upd = 0, c_src = 0, c_str = 0, c_mac = 0;
+
+    /* b2[pinv[i]] = b[i]  (SLIP_LU_solve.c:68-75): rows keep their ids, the bitmap is indexed by position */
+    for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
+    if (tid == 0) { sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_NROWS] = 0; sv[SV_F] = n; }
+    slip_block_sync();
+    for (int i = tid; i < n; i += T) {
+        const int32_t bl = A.blen[(int64_t) c * n + i];
+        SlipRow r; r.len = bl; r.h = -1; r.tag = tag; r.bits = 0;
+        if (bl != 0) {
+            const int pos = P.pinv[i], lb = slip_abs(bl);
+            slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
+            const dig_t *src = (const dig_t *)(A.blimbs + A.boff[(int64_t) c * n + i]);
+            dig_t *X = P.xd + (int64_t) i * P.xcap;
+            if (lb > P.xcap) sv[SV_ERR] = 1;
+            else {
+                const int lw = (lb + 1) & ~1;
+                for (int d = 0; d < lw; d++) X[d] = d < lb ? src[d] : 0u;
+                r.bits = 32 * lb - slip_clz32(src[lb - 1]);
+            }
+            P.xrow[i] = r;
+        }
+    }
+    slip_block_sync();
+    if (sv[SV_ERR]) return SLIPDEV_GROW_X;
+
+    /* forward substitution = the sweep over ALL pivot positions (slip_forward_sub.c:61-158) */
+    slip_sweep<FAST, false>(P, st, n, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac);
+    slip_block_sync();
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+
+    /* x <- x * det (slip_array_mul.c:19), det = rho[n-1] */
+    int npat, nUdummy;
+    slip_pattern(P, lds, bm, n, &npat, &nUdummy);
+    const int32_t *patl = (const int32_t *)(lds + SLIP_LDS_PAT);
+    auto pat_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? patl[t] : P.pat[t]; };
+    slip_block_sync();
+    {
+        volatile int32_t *wcnt = &sv[SV_CNT0];
+        if (tid == 0) *wcnt = 0;
+        slip_block_sync();
+        const SlipPiv Mdet = slip_ld_piv(&P.piv[n - 1]);
+        for (int t0 = 0; t0 < npat; t0 += SLIP_WORK_CAP) {
+            const int te = t0 + SLIP_WORK_CAP < npat ? t0 + SLIP_WORK_CAP : npat;
+            for (int tb = t0; tb < te; tb += T) {
+                const int t = tb + tid;
+                int queue = 0, r = 0;
+                if (t < te) do {
+                    r = P.row_perm[pat_at(t)];
+                    const SlipRow xr = P.xrow[r];
+                    if (xr.len == 0) break;
+                    slip_u128 y = 0; int ys = 1; int done = 0;
+                    if (slip_abs(xr.len) <= 2) {
+                        const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                        if (slip_history_small(P, xr, xv, Mdet, -1, &y, &ys)) { slip_store_small(P, r, y, ys, xr.h, tag); done = 1; }
+                    }
+                    if (!done) queue = 1;
+                } while (0);
+                /* queue slots per wave (one LDS atomic per wave, not per row on the same counter) */
+                const uint64_t qm = slip_ballot(queue);
+                int qbase = 0;
+                if (lane == 0 && qm) qbase = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(qm));
+                qbase = (int) slip_shfl_u32((uint32_t) qbase, 0);
+                if (queue) work[qbase + slip_popc64(qm & ((1ull << lane) - 1ull))] = (uint32_t) r;
+            }
+            slip_block_sync();
+            slip_drain(P, lds, 4, 0, 0, n, 0, *wcnt, work, b0, b1, b2);
+            if (tid == 0) *wcnt = 0;
+            slip_block_sync();
+        }
+    }
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+
+    /* back substitution (slip_back_sub.c:36-52): positions descending; x_j /= U_jj (= rho_j, the last entry
+     * of U(:,j)), then x_i -= U_ij x_j for the rows above */
+    {
+        volatile int32_t *wcnt = &sv[SV_CNT0];
+        int cur = n;
+        for (;;) {
+            slip_block_sync();
+            const int jp = slip_bitmap_prev(bm, cur);
+            if (jp < 0) break;
+            cur = jp;
+            const int j = P.row_perm[jp];
+            SlipRow xj = P.xrow[j];
+            if (xj.tag != tag || xj.len == 0) continue;
+            const SlipPiv Dj = slip_ld_piv(&P.piv[jp]);
+            if (slip_abs(xj.len) <= 2 && slip_abs(Dj.len) <= 2) {
+                const slip_u128 y = slip_divexact128((slip_u128) slip_limb0(P.xd + (int64_t) j * P.xcap), Dj.lo, Dj.ctz, Dj.inv64);
+                slip_block_sync();                                 /* every thread has read the old value */
+                if (tid == 0) slip_store_small(P, j, y, slip_sgn(xj.len) * slip_sgn(Dj.len), xj.h, tag);
+            } else {
+                slip_block_sync();
+                if (wave == 0) { const int e = slip_divexact_out(&P, j, jp, b0, b1, b2); if (e && lane == 0) sv[SV_ERR] = e; }
+            }
+            slip_block_sync();
+            if (sv[SV_ERR]) break;
+            xj = P.xrow[j];
+            const uint64_t xjv = slip_limb0(P.xd + (int64_t) j * P.xcap);
+            const int64_t m0 = P.Up[jp], m1 = P.Up[jp + 1] - 1;   /* the pivot is the last entry */
+            for (int64_t mb = m0; mb < m1; mb += SLIP_WORK_CAP) {
+                const int64_t me = mb + SLIP_WORK_CAP < m1 ? mb + SLIP_WORK_CAP : m1;
+                for (int64_t mm = mb; mm < me; mm += T) {
+                    const int64_t m = mm + tid;
+                    int queue = 0, qi = 0;
+                    if (m < me) do {
+                    const int i = P.Ui[m];
+                    const SlipEnt ue = P.Ue[m];
+                    const int pos = P.pinv[i];
+                    SlipRow xi = P.xrow[i];
+                    if (xi.tag != tag) {
+                        xi.len = 0; xi.h = -1; xi.bits = 0; xi.tag = tag; P.xrow[i] = xi;
+                        slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
+                    }
+                    if (ue.len == 0) break;
+                    int done = 0;
+                    if (slip_abs(ue.len) <= 2 && slip_abs(xj.len) <= 2 && slip_abs(xi.len) <= 2) {
+                        const int bt = (xi.bits > ue.bits + xj.bits ? xi.bits : ue.bits + xj.bits) + 1;
+                        if (bt <= 126) {
+                            const slip_u128 p2 = (slip_u128) slip_limb0((const dig_t *)(P.Ulimbs + ue.off)) * xjv;
+                            const int s2 = slip_sgn(ue.len) * slip_sgn(xj.len), sx = slip_sgn(xi.len);
+                            slip_u128 mag; int sT;
+                            if (xi.len == 0) { mag = p2; sT = -s2; }
+                            else {
+                                const slip_u128 xv = (slip_u128) slip_limb0(P.xd + (int64_t) i * P.xcap);
+                                if (sx == s2) { if (xv >= p2) { mag = xv - p2; sT = sx; } else { mag = p2 - xv; sT = -sx; } }
+                                else { mag = xv + p2; sT = sx; }
+                            }
+                            slip_store_small(P, i, mag, sT, xi.h, tag);
+                            done = 1;
+                        }
+                    }
+                    if (!done) { queue = 1; qi = i; }
+                    } while (0);
+                    const uint64_t qm = slip_ballot(queue);          /* queue slots per wave */
+                    int qbase = 0;
+                    if (lane == 0 && qm) qbase = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(qm));
+                    qbase = (int) slip_shfl_u32((uint32_t) qbase, 0);
+                    if (queue) {
+                        const int at = qbase + slip_popc64(qm & ((1ull << lane) - 1ull));
+                        work[2 * at] = (uint32_t)(m - m0); work[2 * at + 1] = (uint32_t) qi;
+                    }
+                }
+                slip_block_sync();
+                slip_drain(P, lds, 5, j, jp, n, m0, *wcnt, work, b0, b1, b2);
+                if (tid == 0) *wcnt = 0;
+                slip_block_sync();
+                if (sv[SV_ERR]) break;
+            }
+            if (sv[SV_ERR]) break;
+        }
+    }
+    slip_block_sync();
+    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+
+    /* output: numerators in pivot-position order (the order SLIP_LU_solve returns before SLIP_permute_x); every
+     * right-hand side owns a region of the output slab */
+    {
+        const int64_t obase = (int64_t) c * A.ostride;
+        uint64_t run = 0;
+        for (int p0 = 0; p0 < n; p0 += T) {
+            const int pos = p0 + tid;
+            int32_t xl = 0; int r = -1;
+            if (pos < n && ((bm[pos >> 5] >> (pos & 31)) & 1u)) { r = P.row_perm[pos]; xl = P.xrow[r].len; }
+            uint64_t e0, e1, t0_, t1_;
+            slip_block_scan2((uint64_t) slip_limbs(xl), 0, scan_tmp, &e0, &e1, &t0_, &t1_);
+            if (pos < n) {
+                const int64_t off = obase + (int64_t)(run + e0);
+                A.olen[(int64_t) c * n + pos] = xl;
+                A.ooff[(int64_t) c * n + pos] = off;
+                if (xl != 0 && (int64_t)(run + e0) + slip_limbs(xl) <= A.ostride) {
+                    const dig_t *src = P.xd + (int64_t) r * P.xcap;
+                    dig_t *dst = (dig_t *)(A.olimbs + off);
+                    const int lw = (slip_abs(xl) + 1) & ~1;
+                    for (int d = 0; d < lw; d++) dst[d] = src[d];
+                }
+            }
+            run += t0_;
+        }
+        if ((int64_t) run > A.ostride) return SLIPDEV_GROW_U;       /* output region too small: the host grows it */
+    }
+    slip_block_sync();
+    return SLIPDEV_OK;
+}
+
+/* kernel body of the solves: every workgroup draws right-hand sides from the ticket counter (they are independent,
+ * slip_forward_sub.c:61-158 per column of b); rhs_done[c] marks the finished ones so that a relaunch after a grow
+ * only repeats the others */
+template <bool FAST>
+SLIP_DEV void slip_solve_worker(const SlipParams &P, SlipState *st, const SlipSolveArgs &A, int32_t *rhs_done, uint32_t *lds)
+{
+    const int tid = slip_tid();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    for (;;) {
+        slip_block_sync();
+        if (tid == 0) {
+            const int t = slip_agent_add_i32(&st->ticket, 1);
+            sv[SV_K] = t - P.t0; sv[SV_TAG] = t + 1;
+        }
+        slip_block_sync();
+        const int c = sv[SV_K], tag = sv[SV_TAG];
+        if (c >= A.nrhs) break;
+        if (rhs_done[c]) continue;
+        const int status = slip_solve_rhs<FAST>(P, st, A, c, tag, lds);
+        if (tid == 0) {
+            if (status == SLIPDEV_OK) rhs_done[c] = 1;
+            else slip_raise_stop(st, c, status);
+        }
+    }
+}
+
+#endif /* SLIP_REF_LU_PIPE_COLS_H */

@@ -2,17 +2,17 @@
  * C ABI declared in include/slip_hip.h.
  *
  * Host responsibilities (the part of SLIP_LU/Source/SLIP_LU_factorize.c:58-211
- * that is not arithmetic): validate, upload A and q once, size the dense
- * scatter vector / L / U slabs in HBM, launch the column-loop kernel, and grow
- * a buffer and relaunch from the interrupted column when the kernel asks
- * (the reference doubles L/U at :200-211 and lets GMP realloc x).
+ * that is not arithmetic): validate, upload A and q once, size the workers'
+ * private scatter vectors and the shared L / U slabs in HBM, launch the grid of
+ * column workers (ref_lu_pipe.h), and grow a buffer and relaunch from the first
+ * uncommitted column when the kernel asks (the reference doubles L/U at
+ * :200-211 and lets GMP realloc x).
  *
  * Built by hipcc for gfx950.  With -DSLIP_EMULATE (tests/emu, g++) the same
  * source runs the kernel lane-by-lane on the CPU for unit tests; that build is
  * never the product.
  */
-#include "ref_lu_kernel.h"
-#include "wave_bigint_reg.h"
+#include "ref_lu_pipe.h"
 #include "slip_matgen.h"
 #include "../../include/slip_hip.h"
 
@@ -67,27 +67,58 @@ SLIP_DEV void slip_reg_op_test(int op, const uint32_t *A, int la, const uint32_t
     else slip_reg_op_test_d<4>(op, A, la, B, lb, W, O, scratch);
 }
 
+/* a worker's view of the parameters: the private arrays start at this workgroup's share */
+SLIP_DEV void slip_worker_params(SlipParams *Pw, const SlipParams &P, int worker)
+{
+    *Pw = P;
+    Pw->worker = worker;
+    Pw->xrow = P.xrow + (int64_t) worker * P.priv_rows;
+    Pw->xd = P.xd + (int64_t) worker * P.priv_rows * P.xcap;
+    Pw->pat = P.pat + (int64_t) worker * P.priv_rows;
+    Pw->rlist = P.rlist + (int64_t) worker * P.priv_rows;
+    Pw->gbitmap = P.gbitmap + (int64_t) worker * (P.bitmap_in_lds ? 0 : P.bm_words + 64);
+    Pw->gscratch = P.gscratch + (int64_t) worker * (P.scratch_in_lds ? 0 : (int64_t) SLIP_SCRATCH_WAVES * 3 * P.wcap);
+}
+
+/* the last worker to leave records where the factorisation stands (the host reads the state once) */
+SLIP_DEV void slip_worker_exit(const SlipParams &P, SlipState *st)
+{
+    slip_block_sync();
+    if (slip_tid() == 0) {
+        if (slip_agent_add_i32(&st->exited, 1) == P.nworkers - 1) {
+            const int F = slip_ld_i32(&st->F);
+            st->k_next = F;
+            st->Lnz = slip_ld_i64(&P.Lp[F]); st->Lnl = slip_ld_i64(&P.Lo[F]);
+            st->Unz = slip_ld_i64(&P.Up[F]); st->Unl = slip_ld_i64(&P.Uo[F]);
+        }
+    }
+}
+
 #ifndef SLIP_EMULATE
-#define SLIP_MAX_WAVES 8                   /* 512 threads: 2 waves per SIMD, 256 VGPRs per lane */
+#define SLIP_MAX_WAVES 8                   /* at most 512 threads per worker: 256 VGPRs per lane, two waves per SIMD */
 template <bool FAST>
 __global__ void __launch_bounds__(64 * SLIP_MAX_WAVES)
 slip_factor_kernel(SlipParams P, SlipState *st)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t slip_lds[];
-    /* the parameters live in LDS for the whole launch: ~75 dwords held in SGPRs across the column loop made the
-     * compiler spill scalars into VGPR lanes all over the lane-level phases */
+    /* the parameters live in LDS for the whole launch (held in SGPRs across the column loop they made the
+     * compiler spill scalars into VGPR lanes all over the lane-level phases); the private arrays are this worker's */
     __shared__ SlipParams sP;
-    if (threadIdx.x == 0) sP = P;
+    if (threadIdx.x == 0) slip_worker_params(&sP, P, (int) blockIdx.x);
     __syncthreads();
-    slip_factor_columns<FAST>(sP, st, slip_lds);     /* block 0: column loop; blocks >= 1: helpers */
+    slip_factor_worker<FAST>(sP, st, slip_lds);
+    slip_worker_exit(sP, st);
 }
 
 template <bool FAST>
 __global__ void __launch_bounds__(64 * SLIP_MAX_WAVES)
-slip_solve_kernel(SlipParams P, SlipState *st, SlipSolveArgs A)
+slip_solve_kernel(SlipParams P, SlipState *st, SlipSolveArgs A, int32_t *rhs_done)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t slip_lds[];
-    slip_solve_all<FAST>(P, st, A, slip_lds);        /* block 0: the right-hand sides; blocks >= 1: helpers */
+    __shared__ SlipParams sP;
+    if (threadIdx.x == 0) slip_worker_params(&sP, P, (int) blockIdx.x);
+    __syncthreads();
+    slip_solve_worker<FAST>(sP, st, A, rhs_done, slip_lds);
 }
 
 /* unit-test kernel: block b performs operation b with one wavefront */
@@ -136,23 +167,24 @@ slip_wave_bench_kernel(int op, int la, int lb, int W, int iters, int out_in_lds,
     if (slip_lane() == 0) cycles[wave] = (t1 - t0) / (unsigned long long) iters;
 }
 #else
-static uint32_t slip_emu_lds[SLIP_LDS_MAX_WORDS + 1024];
+#define SLIP_MAX_WAVES 16                  /* emulation build */
 #endif
 
 /* ------------------------------------------------------------------ */
 /* host state                                                          */
 /* ------------------------------------------------------------------ */
 struct slip_hip_factor {
-    SlipParams P;         /* kernel arguments (device pointers inside)   */
+    SlipParams P;         /* kernel arguments (device pointers inside; private arrays: base of worker 0) */
     SlipState hs;         /* host mirror of the mutable device state     */
     SlipState *ds;        /* device copy the kernel works on             */
-    SlipParams *dP;       /* device copy of P (P.self): read by the out-of-line device routines */
     int32_t n; int64_t annz, alimbs;
     int32_t waves, lds_words, bitmap_in_lds, scratch_in_lds;
+    int32_t nworkers;      /* column workers = workgroups of a launch; private arrays are sized for this many */
     int32_t last_status, window_end, launches;
     int32_t factors_only;  /* built from given factors (slip_hip_factor_from_factors): solve only, no A */
     double kernel_ms, solve_ms;
     hipEvent_t ev0, ev1;
+    int32_t *ident;        /* device: 0..n-1 (reset copies it into pinv / row_perm) */
     /* owned device arrays that are only reachable through const pointers in P */
     int64_t *dAp; int32_t *dAi, *dAlen; int64_t *dAoff; uint64_t *dAlimbs; int32_t *dq;
 };
@@ -178,13 +210,13 @@ template <class T> static int dev_grow(T **p, int64_t old_count, int64_t new_cou
     return 0;
 }
 
-extern "C" const char *slip_hip_version(void) { return "slip_hip 0.1 (gfx950)"; }
+extern "C" const char *slip_hip_version(void) { return "slip_hip 0.2 (gfx950, column-worker pipeline)"; }
 
 extern "C" void slip_hip_default_options(slip_hip_options *o)
 {
     /* SLIP_LU_internal.h:136-149: pivot = SLIP_TOL_SMALLEST, tol = 1 */
     o->pivot = 3; o->tol = 1.0; o->limb_cap = 0; o->waves = 0; o->lnz_hint = 0; o->unz_hint = 0;
-    o->helpers = -1; o->fork_min = 0;
+    o->workers = 0; o->reserved = 0;
 }
 
 extern "C" int slip_hip_device_count(void)
@@ -216,23 +248,71 @@ static void plan_launch(slip_hip_factor *f)
     f->scratch_in_lds = fixed + (int64_t)(nw * 3 + 1) * P->wcap <= SLIP_LDS_MAX_WORDS;
     f->waves = nw;
     f->lds_words = fixed + (f->scratch_in_lds ? (nw * 3 + 1) * P->wcap : 0);
+    P->bitmap_in_lds = f->bitmap_in_lds; P->scratch_in_lds = f->scratch_in_lds;
 }
 
-static int alloc_x(slip_hip_factor *f, int32_t xcap)
+/* how many column workers: as many as can be resident (LDS-limited workgroups per CU times the CUs), capped by the
+ * columns there are and by what their private vectors may take of the HBM */
+static int32_t default_workers(const slip_hip_factor *f, int32_t xcap)
+{
+    int cus = 256;
+#ifndef SLIP_EMULATE
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+#else
+    cus = 3;
+#endif
+    const int64_t lds_bytes = (int64_t) f->lds_words * 4;
+    int per_cu = (int)((160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1));
+    const int by_waves = 16 / (f->waves > 0 ? f->waves : 1);          /* two waves per SIMD */
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    int64_t w = (int64_t) cus * per_cu;
+    const int64_t per_worker = (int64_t) f->n * (16 + 4 * (int64_t) xcap + 8) + 4096;
+    const int64_t budget = 96ll << 30;                                  /* of the 288 GB */
+    if (w * per_worker > budget) w = budget / per_worker;
+    if (w > f->n) w = f->n;
+    if (w < 1) w = 1;
+    return (int32_t) w;
+}
+
+/* the workers' private arrays (x rows and their digits, pattern overflow, row lists, HBM bitmap / scratch) and the
+ * shared inverse cache for stride xcap */
+static int alloc_x(slip_hip_factor *f, int32_t xcap, int keep_rows)
 {
     SlipParams *P = &f->P;
     if (P->xd) hipFree(P->xd);
     if (P->invd) hipFree(P->invd);
     if (P->gscratch) hipFree(P->gscratch);
-    P->xd = NULL; P->invd = NULL; P->gscratch = NULL;
+    if (P->gbitmap) hipFree(P->gbitmap);
+    P->xd = NULL; P->invd = NULL; P->gscratch = NULL; P->gbitmap = NULL;
     xcap = (xcap + 3) & ~3;
     P->xcap = xcap; P->invcap = xcap + 8;
-    if (dev_alloc(&P->xd, (int64_t) P->n * xcap)) return SLIP_HIP_OUT_OF_MEMORY;
-    if (dev_alloc(&P->invd, (int64_t) P->n * P->invcap)) return SLIP_HIP_OUT_OF_MEMORY;
-    /* cached inverses are gone: pivots recompute them on demand (invlen = 0) */
-    if (hipMemset(P->piv, 0, (size_t) P->n * sizeof(SlipPiv)) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
     plan_launch(f);
-    if (dev_alloc(&P->gscratch, (int64_t)(P->nhelpers + 1) * 16 * 3 * P->wcap)) return SLIP_HIP_OUT_OF_MEMORY;
+    if (f->nworkers <= 0) f->nworkers = default_workers(f, xcap);
+    const int64_t W = f->nworkers, n = P->n;
+    P->nworkers = f->nworkers; P->priv_rows = n;
+    if (!keep_rows) {
+        if (P->xrow) hipFree(P->xrow);
+        if (P->pat) hipFree(P->pat);
+        if (P->rlist) hipFree(P->rlist);
+        P->xrow = NULL; P->pat = NULL; P->rlist = NULL;
+        if (dev_alloc(&P->xrow, W * n) || dev_alloc(&P->pat, W * n) || dev_alloc(&P->rlist, W * n)) return SLIP_HIP_OUT_OF_MEMORY;
+        /* tags start at 0 = "belongs to no column"; tickets count from 1 */
+        if (hipMemset(P->xrow, 0, (size_t)(W * n) * sizeof(SlipRow)) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
+    }
+    if (dev_alloc(&P->xd, W * n * xcap)) return SLIP_HIP_OUT_OF_MEMORY;
+    if (dev_alloc(&P->invd, n * (int64_t) P->invcap)) return SLIP_HIP_OUT_OF_MEMORY;
+    if (dev_alloc(&P->gscratch, f->scratch_in_lds ? 1 : W * SLIP_SCRATCH_WAVES * 3 * (int64_t) P->wcap)) return SLIP_HIP_OUT_OF_MEMORY;
+    if (dev_alloc(&P->gbitmap, f->bitmap_in_lds ? 1 : W * ((int64_t) P->bm_words + 64))) return SLIP_HIP_OUT_OF_MEMORY;
+    return 0;
+}
+
+static int upload_state(slip_hip_factor *f, hipStream_t stream)
+{
+    CK(hipMemcpyAsync(f->ds, &f->hs, sizeof(SlipState), hipMemcpyHostToDevice, stream));
     return 0;
 }
 
@@ -241,20 +321,19 @@ extern "C" int slip_hip_factor_reset(slip_hip_factor *f)
     if (!f || f->factors_only) return SLIP_HIP_INCORRECT_INPUT;
     SlipParams *P = &f->P;
     const int32_t n = f->n;
-    int32_t *id = (int32_t *) malloc((size_t) n * 4);
-    if (!id) return SLIP_HIP_OUT_OF_MEMORY;
-    for (int32_t i = 0; i < n; i++) id[i] = i;
-    CK(hipMemcpy(P->pinv, id, (size_t) n * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(P->row_perm, id, (size_t) n * 4, hipMemcpyHostToDevice));
-    free(id);
-    CK(hipMemset(P->Lp, 0, 8));
-    CK(hipMemset(P->Up, 0, 8));
+    CK(hipMemcpyAsync(P->pinv, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
+    CK(hipMemcpyAsync(P->row_perm, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
+    CK(hipMemsetAsync(P->Lready, 0, (size_t) n * 4, 0));
+    CK(hipMemsetAsync(P->Lp, 0, 8, 0)); CK(hipMemsetAsync(P->Up, 0, 8, 0));
+    CK(hipMemsetAsync(P->Lo, 0, 8, 0)); CK(hipMemsetAsync(P->Uo, 0, 8, 0));
     {
-        const int32_t seq = f->hs.seq;                 /* the hand-off generation never goes back */
+        const int32_t ticket = f->hs.ticket;           /* the tickets (= row tags) never go back */
         memset(&f->hs, 0, sizeof f->hs);
-        f->hs.seq = seq;
+        f->hs.ticket = ticket;
+        f->hs.stop = INT64_MAX;
     }
-    CK(hipMemcpy(f->ds, &f->hs, sizeof(SlipState), hipMemcpyHostToDevice));
+    { const int e = upload_state(f, 0); if (e) return e; }
+    CK(hipStreamSynchronize(0));
     f->last_status = 0; f->window_end = 0; f->kernel_ms = 0; f->launches = 0;
     return SLIP_HIP_OK;
 }
@@ -266,13 +345,34 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
     hipFree(f->dAp); hipFree(f->dAi); hipFree(f->dAlen); hipFree(f->dAoff); hipFree(f->dAlimbs); hipFree(f->dq);
     hipFree(P->pinv); hipFree(P->row_perm); hipFree(P->xrow); hipFree(P->xd);
     hipFree(P->piv); hipFree(P->invd);
-    hipFree(P->Lp); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
-    hipFree(P->Up); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
-    hipFree(P->pat); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->batch); hipFree(P->batch_items); hipFree(P->dbg);
-    hipFree(f->ds); hipFree(f->dP);
+    hipFree(P->Lp); hipFree(P->Lo); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
+    hipFree(P->Up); hipFree(P->Uo); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
+    hipFree(P->Lready); hipFree(P->pat); hipFree(P->rlist); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg);
+    hipFree(f->ds); hipFree(f->ident);
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
     free(f);
+}
+
+/* options -> the handle's launch shape */
+static void apply_options(slip_hip_factor *f, const slip_hip_options &opt)
+{
+    f->waves = opt.waves > 0 ? opt.waves : 4;
+    if (f->waves > SLIP_MAX_WAVES) f->waves = SLIP_MAX_WAVES;
+    f->nworkers = opt.workers > 0 ? opt.workers : 0;      /* 0: chosen in alloc_x once the LDS need is known */
+    if (f->nworkers > 4096) f->nworkers = 4096;
+}
+
+static int make_ident(slip_hip_factor *f)
+{
+    const int32_t n = f->n;
+    int32_t *id = (int32_t *) malloc((size_t) n * 4);
+    if (!id) return SLIP_HIP_OUT_OF_MEMORY;
+    for (int32_t i = 0; i < n; i++) id[i] = i;
+    int rc = dev_alloc(&f->ident, n);
+    if (!rc && hipMemcpy(f->ident, id, (size_t) n * 4, hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    free(id);
+    return rc;
 }
 
 extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
@@ -345,17 +445,7 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     if (!f) { free(hAp); free(hAi); free(hAlen); free(hAoff); free(hAlimbs); return SLIP_HIP_OUT_OF_MEMORY; }
     SlipParams *P = &f->P;
     f->n = n; f->annz = onz; f->alimbs = ol;
-    f->waves = opt.waves > 0 ? opt.waves : 8;
-    /* helper workgroups for multi-limb batches: default 63 (64 of the 256 CUs), 0 disables */
-    P->nhelpers = opt.helpers < 0 ? 63 : (opt.helpers > 255 ? 255 : opt.helpers);
-    P->fork_min = opt.fork_min > 0 ? opt.fork_min : (P->nhelpers > 0 ? 24 : 0);
-#ifdef SLIP_EMULATE
-    P->nhelpers = 0;                                   /* the emulator runs one workgroup at a time */
-#endif
-#ifndef SLIP_MAX_WAVES
-#define SLIP_MAX_WAVES 16                  /* emulation build */
-#endif
-    if (f->waves > SLIP_MAX_WAVES) f->waves = SLIP_MAX_WAVES;
+    apply_options(f, opt);
     P->n = n; P->pivot_scheme = opt.pivot; P->limb_cap = opt.limb_cap;
     if (!(opt.tol > 0)) { P->tol_mode = 0; P->tol_m = 0; P->tol_e = 0; }
     else {
@@ -366,12 +456,11 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
 #define A_(call) do { if (!rc) rc = (call); } while (0)
     A_(dev_alloc(&f->dAp, (int64_t) n + 1)); A_(dev_alloc(&f->dAi, onz)); A_(dev_alloc(&f->dAlen, onz));
     A_(dev_alloc(&f->dAoff, onz)); A_(dev_alloc(&f->dAlimbs, ol)); A_(dev_alloc(&f->dq, n));
-    A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n)); A_(dev_alloc(&P->xrow, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->pat, n));
-    A_(dev_alloc(&P->gbitmap, (int64_t)(n + 31) / 32 + 64));
-    A_(dev_alloc(&P->batch, 1)); A_(dev_alloc(&P->batch_items, SLIP_WORK_WORDS)); A_(dev_alloc(&P->dbg, 4 * 256));
+    A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 4 * 256));
+    A_(make_ident(f));
     if (!rc && hipMemset(P->dbg, 0, 4 * 256 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
-    if (!rc && hipMemset(P->batch, 0, sizeof(SlipBatch)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->piv, 0, (size_t) n * sizeof(SlipPiv)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     /* initial sizes: S->lnz/unz only size the first allocation in the reference too */
     P->Lcap_nz = opt.lnz_hint > 0 ? opt.lnz_hint : 4 * onz + n;
     P->Ucap_nz = opt.unz_hint > 0 ? opt.unz_hint : 4 * onz + n;
@@ -381,12 +470,12 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     int32_t xcap0 = cap_digits > 0 ? cap_digits : (2 * maxdig + 8 > 16 ? 2 * maxdig + 8 : 16);
     P->Lcap_nl = P->Lcap_nz * 2;
     P->Ucap_nl = P->Ucap_nz * 2;
-    A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Li, P->Lcap_nz)); A_(dev_alloc(&P->Le, P->Lcap_nz));
+    A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Lo, (int64_t) n + 1)); A_(dev_alloc(&P->Li, P->Lcap_nz)); A_(dev_alloc(&P->Le, P->Lcap_nz));
     A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
-    A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, P->Ucap_nz)); A_(dev_alloc(&P->Ue, P->Ucap_nz));
+    A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Uo, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, P->Ucap_nz)); A_(dev_alloc(&P->Ue, P->Ucap_nz));
     A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
-    A_(dev_alloc(&f->ds, 1)); A_(dev_alloc(&f->dP, 1));
-    if (!rc) rc = alloc_x(f, xcap0);
+    A_(dev_alloc(&f->ds, 1));
+    if (!rc) rc = alloc_x(f, xcap0, 0);
 #undef A_
     if (!rc) {
         if (hipMemcpy(f->dAp, hAp, ((size_t) n + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
@@ -394,20 +483,19 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
             hipMemcpy(f->dAlen, hAlen, (size_t) onz * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(f->dAoff, hAoff, (size_t) onz * 8, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(f->dAlimbs, hAlimbs, (size_t) ol * 8, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(f->dq, q, (size_t) n * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemset(P->xrow, 0, (size_t) n * sizeof(SlipRow)) != hipSuccess)
+            hipMemcpy(f->dq, q, (size_t) n * 4, hipMemcpyHostToDevice) != hipSuccess)
             rc = SLIP_HIP_DEVICE_ERROR;
     }
     free(hAp); free(hAi); free(hAlen); free(hAoff); free(hAlimbs);
     P->Ap = f->dAp; P->Ai = f->dAi; P->Alen = f->dAlen; P->Aoff = f->dAoff; P->Alimbs = f->dAlimbs; P->q = f->dq;
     if (!rc && (hipEventCreate(&f->ev0) != hipSuccess || hipEventCreate(&f->ev1) != hipSuccess)) rc = SLIP_HIP_DEVICE_ERROR;
-    if (!rc) rc = slip_hip_factor_reset(f);
+    if (!rc) { f->hs.ticket = 0; rc = slip_hip_factor_reset(f); }
     if (rc) { slip_hip_factor_destroy(f); return rc; }
     *out = f;
     return SLIP_HIP_OK;
 }
 
-/* new stride of the dense vector; x and the inverse cache are scratch, the pivot records of the
+/* new stride of the dense vectors; x and the inverse cache are scratch, the pivot records of the
  * K committed columns survive (their cached inverses are recomputed on demand) */
 static int grow_x_keep(slip_hip_factor *f, int64_t xcap, int32_t K)
 {
@@ -419,7 +507,10 @@ static int grow_x_keep(slip_hip_factor *f, int64_t xcap, int32_t K)
         if (!keep) return SLIP_HIP_OUT_OF_MEMORY;
         if (hipMemcpy(keep, P->piv, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(keep); return SLIP_HIP_DEVICE_ERROR; }
     }
-    int e = alloc_x(f, (int32_t) xcap);
+    /* a wider stride may change how many workers fit; fewer never hurts, so the count only shrinks */
+    const int32_t old_workers = f->nworkers;
+    int e = alloc_x(f, (int32_t) xcap, 1);
+    if (!e && f->nworkers > old_workers) f->nworkers = f->P.nworkers = old_workers;
     if (!e && K > 0) {
         for (int32_t k = 0; k < K; k++) keep[k].invlen = 0;
         if (hipMemcpy(P->piv, keep, (size_t) K * sizeof(SlipPiv), hipMemcpyHostToDevice) != hipSuccess) e = SLIP_HIP_DEVICE_ERROR;
@@ -428,23 +519,25 @@ static int grow_x_keep(slip_hip_factor *f, int64_t xcap, int32_t K)
     return e;
 }
 
-/* the kernel gets P by value; the out-of-line device routines read the same values through P.self */
-static int upload_params(slip_hip_factor *f, hipStream_t stream)
-{
-    f->P.self = f->dP;
-    CK(hipMemcpyAsync(f->dP, &f->P, sizeof(SlipParams), hipMemcpyHostToDevice, stream));
-    return 0;
-}
+#ifdef SLIP_EMULATE
+static unsigned long long slip_emu_seed = 1;
+extern "C" void slip_emu_set_seed(unsigned long long s) { slip_emu_seed = s; }
+#endif
 
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
-    f->P.seq0 = f->hs.seq;
-    f->P.bitmap_in_lds = f->bitmap_in_lds; f->P.scratch_in_lds = f->scratch_in_lds;
-    { const int e = upload_params(f, stream); if (e) return e; }
+    f->P.k0 = f->hs.F; f->P.t0 = f->hs.ticket;
+    f->hs.stop = INT64_MAX; f->hs.exited = 0;
+    { const int e = upload_state(f, stream); if (e) return e; }
+    /* no more workers than columns left */
+    int32_t W = f->nworkers;
+    if (W > f->P.k_stop - f->hs.F) W = f->P.k_stop - f->hs.F;
+    if (W < 1) W = 1;
+    f->P.nworkers = W;
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;
-    const dim3 grid(1 + f->P.nhelpers), block(64 * f->waves);
+    const dim3 grid(W), block(64 * f->waves);
 #define SLIP_LAUNCH(FAST) do { \
         CK(hipFuncSetAttribute((const void *) slip_factor_kernel<FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes)); \
         hipLaunchKernelGGL((slip_factor_kernel<FAST>), grid, block, lds_bytes, stream, f->P, f->ds); } while (0)
@@ -453,13 +546,23 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 #undef SLIP_LAUNCH
     CK(hipGetLastError());
 #else
-    f->P.bitmap_in_lds = f->bitmap_in_lds; f->P.scratch_in_lds = f->scratch_in_lds;
-    const SlipParams P = f->P; SlipState *ds = f->ds;
-    const int fast = f->bitmap_in_lds && f->scratch_in_lds;
-    emu::launch(1, 64 * f->waves, [P, ds, fast]() {
-        if (fast) slip_factor_columns<true>(P, ds, slip_emu_lds);
-        else slip_factor_columns<false>(P, ds, slip_emu_lds);
-    });
+    {
+        const SlipParams P = f->P; SlipState *ds = f->ds;
+        const int fast = f->bitmap_in_lds && f->scratch_in_lds;
+        const size_t words = (size_t) f->lds_words + 64;
+        uint32_t *lds_all = (uint32_t *) calloc((size_t) W * words, 4);
+        if (!lds_all) return SLIP_HIP_OUT_OF_MEMORY;
+        emu::set_seed(slip_emu_seed);
+        emu::launch(W, 64 * f->waves, [P, ds, fast, lds_all, words]() {
+            SlipParams Pw;
+            slip_worker_params(&Pw, P, slip_block());
+            uint32_t *lds = lds_all + (size_t) slip_block() * words;
+            if (fast) slip_factor_worker<true>(Pw, ds, lds);
+            else slip_factor_worker<false>(Pw, ds, lds);
+            slip_worker_exit(Pw, ds);
+        });
+        free(lds_all);
+    }
 #endif
     CK(hipEventRecord(f->ev1, stream));
     CK(hipMemcpyAsync(&f->hs, f->ds, sizeof(SlipState), hipMemcpyDeviceToHost, stream));
@@ -468,6 +571,13 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
     CK(hipEventElapsedTime(&ms, f->ev0, f->ev1));
     f->kernel_ms += ms;
     f->launches++;
+    /* where the launch ended: the frontier; why: the stop word, if it names the frontier column */
+    SlipState *h = &f->hs;
+    h->k_next = h->F;
+    h->status = SLIPDEV_OK; h->status_k = h->F;
+    if ((int)(h->stop & 0xFF) == SLIPDEV_INTERNAL) h->status = SLIPDEV_INTERNAL;
+    else if (h->stop != INT64_MAX && (h->stop >> 8) == (int64_t) h->F) h->status = (int)(h->stop & 0xFF);
+    else if (h->F < f->P.k_stop) h->status = SLIPDEV_INTERNAL;       /* the workers left without a reason */
     return 0;
 }
 
@@ -481,7 +591,7 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
     f->kernel_ms = 0; f->launches = 0; f->window_end = 0;
     P->k_stop = kmax;
     int rc = SLIP_HIP_OK;
-    while (h->k_next < kmax) {
+    while (h->F < kmax) {
         int e = launch_columns(f, stream);
         if (e) { rc = e; break; }
         if (h->status == SLIPDEV_OK) continue;
@@ -499,30 +609,17 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
                 (e = dev_grow(&P->Ulimbs, h->Unl, nl))) { rc = e; break; }
             P->Ucap_nz = nz; P->Ucap_nl = nl;
         } else if (h->status == SLIPDEV_GROW_X) {
-            e = grow_x_keep(f, P->xcap * 2, h->k_next);
+            e = grow_x_keep(f, (int64_t) P->xcap * 2, h->F);
             if (e) { rc = e; break; }
         } else {
-            fprintf(stderr, "slip_hip: kernel stopped with internal status %d at column %d\n", h->status, h->status_k);
-            {   /* hand-off diagnostics: who did not answer */
-                int32_t dbg[4 * 256];
-                if (hipMemcpy(dbg, P->dbg, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
-                    fprintf(stderr, "  master: gen %d, done %d of %d, kind %d, items %d\n", dbg[0], dbg[1], P->nhelpers, dbg[2], dbg[3]);
-                    for (int b = 1; b <= P->nhelpers; b++)
-                        if (!(dbg[4 * b] == dbg[0] + 1 && dbg[4 * b + 1] == 4))
-                            fprintf(stderr, "  helper %d: gen %d stage %d kind %d items %d\n", b, dbg[4 * b], dbg[4 * b + 1], dbg[4 * b + 2], dbg[4 * b + 3]);
-                    SlipBatch hb;
-                    if (hipMemcpy(&hb, P->batch, sizeof hb, hipMemcpyDeviceToHost) == hipSuccess)
-                        fprintf(stderr, "  batch: seq %d done %d err %d kind %d stamp %d stale_seen %d\n", hb.seq, hb.done, hb.err, hb.kind, hb.stamp, hb.stale_seen);
-                }
-            }
+            fprintf(stderr, "slip_hip: kernel stopped with internal status %d at column %d (frontier %d, ready %d, stop %lld)\n",
+                    h->status, h->status_k, h->F, h->F2, (long long) h->stop);
             rc = SLIP_HIP_DEVICE_ERROR; break;
         }
     }
     f->last_status = rc;
     return rc;
 }
-
-
 
 /* ---- a handle around GIVEN factors (the caller's L, U, pinv): what SLIP_LU_solve receives ---- */
 static int slab_to_entries(int64_t nz, const int32_t *len, const uint64_t *limbs, SlipEnt *ent, int32_t *maxdig, int64_t *nl_out)
@@ -562,7 +659,8 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     int32_t *rowperm = (int32_t *) malloc((size_t) n * 4);
     SlipEnt *Le = (SlipEnt *) malloc((size_t) lnz * sizeof(SlipEnt)), *Ue = (SlipEnt *) malloc((size_t) unz * sizeof(SlipEnt));
     SlipPiv *piv = (SlipPiv *) calloc((size_t) n, sizeof(SlipPiv));
-    if (!rowperm || !Le || !Ue || !piv) { free(rowperm); free(Le); free(Ue); free(piv); return SLIP_HIP_OUT_OF_MEMORY; }
+    int64_t *Lo = (int64_t *) malloc(((size_t) n + 1) * 8), *Uo = (int64_t *) malloc(((size_t) n + 1) * 8);
+    if (!rowperm || !Le || !Ue || !piv || !Lo || !Uo) { free(rowperm); free(Le); free(Ue); free(piv); free(Lo); free(Uo); return SLIP_HIP_OUT_OF_MEMORY; }
     int bad = 0;
     for (int32_t i = 0; i < n; i++) rowperm[i] = -1;
     for (int32_t i = 0; i < n && !bad; i++) { if (pinv[i] < 0 || pinv[i] >= n || rowperm[pinv[i]] >= 0) bad = 1; else rowperm[pinv[i]] = i; }
@@ -584,76 +682,84 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
         if (dig <= 2) { uint64_t d = pr.lo >> z, x = d; for (int r = 0; r < 5; r++) x *= 2 - d * x; pr.inv64 = x; }
         piv[k] = pr;
     }
-    if (bad) { free(rowperm); free(Le); free(Ue); free(piv); return SLIP_HIP_INCORRECT_INPUT; }
+    if (!bad) for (int32_t k = 0; k <= n; k++) { Lo[k] = k < n ? Le[Lp[k]].off : lnl; Uo[k] = k < n ? Ue[Up[k]].off : unl; }
+    if (bad) { free(rowperm); free(Le); free(Ue); free(piv); free(Lo); free(Uo); return SLIP_HIP_INCORRECT_INPUT; }
 
     slip_hip_factor *f = (slip_hip_factor *) calloc(1, sizeof(slip_hip_factor));
-    if (!f) { free(rowperm); free(Le); free(Ue); free(piv); return SLIP_HIP_OUT_OF_MEMORY; }
+    if (!f) { free(rowperm); free(Le); free(Ue); free(piv); free(Lo); free(Uo); return SLIP_HIP_OUT_OF_MEMORY; }
     SlipParams *P = &f->P;
     f->n = n; f->factors_only = 1;
-    f->waves = opt.waves > 0 ? opt.waves : 8;
-    P->nhelpers = opt.helpers < 0 ? 63 : (opt.helpers > 255 ? 255 : opt.helpers);
-    P->fork_min = opt.fork_min > 0 ? opt.fork_min : (P->nhelpers > 0 ? 24 : 0);
-#ifdef SLIP_EMULATE
-    P->nhelpers = 0;
-#endif
-    if (f->waves > SLIP_MAX_WAVES) f->waves = SLIP_MAX_WAVES;
+    apply_options(f, opt);
+    if (f->nworkers <= 0) f->nworkers = 64;            /* right-hand sides in flight; more are taken in turn */
     P->n = n; P->pivot_scheme = opt.pivot; P->limb_cap = 0; P->k_stop = n;
     P->Lcap_nz = lnz; P->Ucap_nz = unz; P->Lcap_nl = lnl > 0 ? lnl : 1; P->Ucap_nl = unl > 0 ? unl : 1;
     int rc = 0;
 #define A_(call) do { if (!rc) rc = (call); } while (0)
-    A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n)); A_(dev_alloc(&P->xrow, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->pat, n));
-    A_(dev_alloc(&P->gbitmap, (int64_t)(n + 31) / 32 + 64));
-    A_(dev_alloc(&P->batch, 1)); A_(dev_alloc(&P->batch_items, SLIP_WORK_WORDS)); A_(dev_alloc(&P->dbg, 4 * 256));
-    A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Li, lnz)); A_(dev_alloc(&P->Le, lnz)); A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
-    A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, unz)); A_(dev_alloc(&P->Ue, unz)); A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
-    A_(dev_alloc(&f->ds, 1)); A_(dev_alloc(&f->dP, 1));
-    if (!rc && (hipMemset(P->dbg, 0, 4 * 256 * 4) != hipSuccess || hipMemset(P->batch, 0, sizeof(SlipBatch)) != hipSuccess ||
-                hipMemset(P->xrow, 0, (size_t) n * sizeof(SlipRow)) != hipSuccess)) rc = SLIP_HIP_DEVICE_ERROR;
-    if (!rc) rc = alloc_x(f, 2 * maxdig + 8);                 /* clears piv: upload the records afterwards */
+    A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 4 * 256));
+    A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Lo, (int64_t) n + 1)); A_(dev_alloc(&P->Li, lnz)); A_(dev_alloc(&P->Le, lnz)); A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
+    A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Uo, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, unz)); A_(dev_alloc(&P->Ue, unz)); A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
+    A_(dev_alloc(&f->ds, 1));
+    if (!rc && hipMemset(P->dbg, 0, 4 * 256 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc) rc = alloc_x(f, 2 * maxdig + 8, 0);
 #undef A_
 #define UP_(dst, src, bytes) do { if (!rc && (bytes) > 0 && hipMemcpy((void *)(dst), (src), (size_t)(bytes), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR; } while (0)
     UP_(P->pinv, pinv, (size_t) n * 4); UP_(P->row_perm, rowperm, (size_t) n * 4); UP_(P->piv, piv, (size_t) n * sizeof(SlipPiv));
-    UP_(P->Lp, Lp, ((size_t) n + 1) * 8); UP_(P->Li, Li, (size_t) lnz * 4); UP_(P->Le, Le, (size_t) lnz * sizeof(SlipEnt)); UP_(P->Llimbs, Llimbs, (size_t) lnl * 8);
-    UP_(P->Up, Up, ((size_t) n + 1) * 8); UP_(P->Ui, Ui, (size_t) unz * 4); UP_(P->Ue, Ue, (size_t) unz * sizeof(SlipEnt)); UP_(P->Ulimbs, Ulimbs, (size_t) unl * 8);
+    UP_(P->Lp, Lp, ((size_t) n + 1) * 8); UP_(P->Lo, Lo, ((size_t) n + 1) * 8); UP_(P->Li, Li, (size_t) lnz * 4); UP_(P->Le, Le, (size_t) lnz * sizeof(SlipEnt)); UP_(P->Llimbs, Llimbs, (size_t) lnl * 8);
+    UP_(P->Up, Up, ((size_t) n + 1) * 8); UP_(P->Uo, Uo, ((size_t) n + 1) * 8); UP_(P->Ui, Ui, (size_t) unz * 4); UP_(P->Ue, Ue, (size_t) unz * sizeof(SlipEnt)); UP_(P->Ulimbs, Ulimbs, (size_t) unl * 8);
     if (!rc && (hipEventCreate(&f->ev0) != hipSuccess || hipEventCreate(&f->ev1) != hipSuccess)) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc) {
         memset(&f->hs, 0, sizeof f->hs);
-        f->hs.k_next = n; f->hs.Lnz = lnz; f->hs.Unz = unz; f->hs.Lnl = lnl; f->hs.Unl = unl; f->hs.Lnl_exact = lnl;
+        f->hs.F = n; f->hs.F2 = n; f->hs.stop = INT64_MAX;
+        f->hs.k_next = n; f->hs.Lnz = lnz; f->hs.Unz = unz; f->hs.Lnl = lnl; f->hs.Unl = unl; f->hs.Lnl_exact = lnl; f->hs.Unl_exact = unl;
         f->hs.c_maxdig = (unsigned long long) maxdig;
         UP_(f->ds, &f->hs, sizeof(SlipState));
     }
 #undef UP_
-    free(rowperm); free(Le); free(Ue); free(piv);
+    free(rowperm); free(Le); free(Ue); free(piv); free(Lo); free(Uo);
     if (rc) { slip_hip_factor_destroy(f); return rc; }
     *out = f;
     return SLIP_HIP_OK;
 }
 
 /* ---- REF triangular solves on the resident factors (SLIP_LU_solve.c:41-86) ---- */
-static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, hipStream_t stream)
+static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, int32_t *rhs_done, hipStream_t stream)
 {
-    f->P.seq0 = f->hs.seq;
-    f->P.bitmap_in_lds = f->bitmap_in_lds; f->P.scratch_in_lds = f->scratch_in_lds;
-    { const int e = upload_params(f, stream); if (e) return e; }
+    f->P.t0 = f->hs.ticket;
+    f->hs.stop = INT64_MAX; f->hs.exited = 0;
+    { const int e = upload_state(f, stream); if (e) return e; }
+    int32_t W = f->nworkers;
+    if (W > A.nrhs) W = A.nrhs;
+    if (W < 1) W = 1;
+    f->P.nworkers = W;
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;
-    const dim3 grid(1 + f->P.nhelpers), block(64 * f->waves);
+    const dim3 grid(W), block(64 * f->waves);
 #define SLIP_LAUNCH(FAST) do { \
         CK(hipFuncSetAttribute((const void *) slip_solve_kernel<FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes)); \
-        hipLaunchKernelGGL((slip_solve_kernel<FAST>), grid, block, lds_bytes, stream, f->P, f->ds, A); } while (0)
+        hipLaunchKernelGGL((slip_solve_kernel<FAST>), grid, block, lds_bytes, stream, f->P, f->ds, A, rhs_done); } while (0)
     if (f->bitmap_in_lds && f->scratch_in_lds) SLIP_LAUNCH(true);
     else SLIP_LAUNCH(false);
 #undef SLIP_LAUNCH
     CK(hipGetLastError());
 #else
-    const SlipParams P = f->P; SlipState *ds = f->ds;
-    const int fast = f->bitmap_in_lds && f->scratch_in_lds;
-    emu::launch(1, 64 * f->waves, [P, ds, fast, A]() {
-        if (fast) slip_solve_all<true>(P, ds, A, slip_emu_lds);
-        else slip_solve_all<false>(P, ds, A, slip_emu_lds);
-    });
+    {
+        const SlipParams P = f->P; SlipState *ds = f->ds;
+        const int fast = f->bitmap_in_lds && f->scratch_in_lds;
+        const size_t words = (size_t) f->lds_words + 64;
+        uint32_t *lds_all = (uint32_t *) calloc((size_t) W * words, 4);
+        if (!lds_all) return SLIP_HIP_OUT_OF_MEMORY;
+        emu::set_seed(slip_emu_seed);
+        emu::launch(W, 64 * f->waves, [P, ds, fast, A, rhs_done, lds_all, words]() {
+            SlipParams Pw;
+            slip_worker_params(&Pw, P, slip_block());
+            uint32_t *lds = lds_all + (size_t) slip_block() * words;
+            if (fast) slip_solve_worker<true>(Pw, ds, A, rhs_done, lds);
+            else slip_solve_worker<false>(Pw, ds, A, rhs_done, lds);
+        });
+        free(lds_all);
+    }
 #endif
     CK(hipEventRecord(f->ev1, stream));
     CK(hipMemcpyAsync(&f->hs, f->ds, sizeof(SlipState), hipMemcpyDeviceToHost, stream));
@@ -670,7 +776,7 @@ extern "C" int slip_hip_factor_solve(slip_hip_factor *f, int32_t nrhs, const int
     if (!f || nrhs <= 0 || !blen || !blimbs || !xlen_out || !xlimbs_out || !xnl_out) return SLIP_HIP_INCORRECT_INPUT;
     *xlen_out = NULL; *xlimbs_out = NULL; *xnl_out = 0;
     const int32_t n = f->n;
-    if (f->hs.k_next != n) return SLIP_HIP_INCORRECT_INPUT;          /* needs the complete factorisation */
+    if (f->hs.F != n) return SLIP_HIP_INCORRECT_INPUT;          /* needs the complete factorisation */
     hipStream_t stream = (hipStream_t) stream_v;
     SlipParams *P = &f->P;
     const int64_t ne = (int64_t) n * nrhs;
@@ -692,72 +798,94 @@ extern "C" int slip_hip_factor_solve(slip_hip_factor *f, int32_t nrhs, const int
     }
     const int64_t bl = o;
     SlipSolveArgs A; memset(&A, 0, sizeof A);
-    int32_t *dblen = NULL, *dolen = NULL; int64_t *dboff = NULL, *dooff = NULL; uint64_t *dbl = NULL, *dol = NULL;
-    int32_t *xl = NULL; uint64_t *xlimbs = NULL;
+    int32_t *dblen = NULL, *dolen = NULL, *ddone = NULL; int64_t *dboff = NULL, *dooff = NULL; uint64_t *dbl = NULL, *dol = NULL;
+    int32_t *xl = NULL, *hdone = NULL; uint64_t *xlimbs = NULL, *raw = NULL; int64_t *hooff = NULL;
     int rc = 0;
     /* x grows to about |b| * det: make room once (the kernel still reports GROW_X if this is short) */
     {
         int64_t want = 2 * ((int64_t) f->hs.c_maxdig + 2) + maxdig + 8;
         if (want > P->xcap) rc = grow_x_keep(f, want, n);
     }
-    int64_t ocap = ne * (((int64_t) f->hs.c_maxdig + maxdig) / 2 + 1) + 64;
+    /* every right-hand side owns `ostride` limbs of the output slab */
+    int64_t ostride = (int64_t) n * (((int64_t) f->hs.c_maxdig + maxdig) / 2 + 1) + 64;
 #define A_(call) do { if (!rc) rc = (call); } while (0)
     A_(dev_alloc(&dblen, ne)); A_(dev_alloc(&dboff, ne)); A_(dev_alloc(&dbl, bl > 0 ? bl : 1));
-    A_(dev_alloc(&dolen, ne)); A_(dev_alloc(&dooff, ne)); A_(dev_alloc(&dol, ocap));
+    A_(dev_alloc(&dolen, ne)); A_(dev_alloc(&dooff, ne)); A_(dev_alloc(&dol, ostride * nrhs)); A_(dev_alloc(&ddone, nrhs));
 #undef A_
+    hdone = (int32_t *) calloc((size_t) nrhs, 4);
+    if (!hdone) rc = rc ? rc : SLIP_HIP_OUT_OF_MEMORY;
     if (!rc && (hipMemcpy(dblen, hlen, (size_t) ne * 4, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(dboff, hoff, (size_t) ne * 8, hipMemcpyHostToDevice) != hipSuccess ||
-                (bl > 0 && hipMemcpy(dbl, blimbs, (size_t) bl * 8, hipMemcpyHostToDevice) != hipSuccess)))
+                (bl > 0 && hipMemcpy(dbl, blimbs, (size_t) bl * 8, hipMemcpyHostToDevice) != hipSuccess) ||
+                hipMemset(ddone, 0, (size_t) nrhs * 4) != hipSuccess))
         rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc) {
         SlipState *h = &f->hs;
-        h->solve_next = 0; h->out_used = 0; h->status = 0;
-        if (hipMemcpy(f->ds, h, sizeof(SlipState), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
         f->solve_ms = 0;
-        A.nrhs = nrhs; A.blen = dblen; A.boff = dboff; A.blimbs = dbl; A.olen = dolen; A.ooff = dooff; A.olimbs = dol; A.ocap = ocap;
-        while (!rc && h->solve_next < nrhs) {
-            int e = launch_solve(f, A, stream);
+        A.nrhs = nrhs; A.blen = dblen; A.boff = dboff; A.blimbs = dbl; A.olen = dolen; A.ooff = dooff; A.olimbs = dol;
+        A.ocap = ostride * nrhs; A.ostride = ostride;
+        for (int guard = 0; !rc && guard < 64; guard++) {
+            int e = launch_solve(f, A, ddone, stream);
             if (e) { rc = e; break; }
-            if (h->status == SLIPDEV_OK) continue;
-            if (h->status == SLIPDEV_GROW_X) rc = grow_x_keep(f, (int64_t) P->xcap * 2, n);
-            else if (h->status == SLIPDEV_GROW_U) {                  /* the output slab */
-                uint64_t *nw = NULL;
-                rc = dev_alloc(&nw, ocap * 2);
-                if (!rc && h->out_used > 0 && hipMemcpy(nw, dol, (size_t) h->out_used * 8, hipMemcpyDeviceToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
-                if (!rc) { hipFree(dol); dol = nw; ocap *= 2; A.olimbs = dol; A.ocap = ocap; } else if (nw) hipFree(nw);
+            if (hipMemcpy(hdone, ddone, (size_t) nrhs * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = SLIP_HIP_DEVICE_ERROR; break; }
+            int all = 1;
+            for (int32_t c = 0; c < nrhs; c++) if (!hdone[c]) all = 0;
+            if (all) break;
+            const int status = h->stop == INT64_MAX ? SLIPDEV_INTERNAL : (int)(h->stop & 0xFF);
+            if (status == SLIPDEV_GROW_X) rc = grow_x_keep(f, (int64_t) P->xcap * 2, n);
+            else if (status == SLIPDEV_GROW_U) {
+                /* the output regions: twice the stride; finished right-hand sides are simply solved again */
+                hipFree(dol); dol = NULL;
+                ostride *= 2;
+                rc = dev_alloc(&dol, ostride * nrhs);
+                if (!rc && hipMemset(ddone, 0, (size_t) nrhs * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+                A.olimbs = dol; A.ocap = ostride * nrhs; A.ostride = ostride;
             } else {
-                fprintf(stderr, "slip_hip: solve kernel stopped with internal status %d at right-hand side %d\n", h->status, h->status_k);
+                fprintf(stderr, "slip_hip: solve kernel stopped with internal status %d (stop %lld)\n", status, (long long) h->stop);
                 rc = SLIP_HIP_DEVICE_ERROR;
             }
         }
     }
     if (!rc) {
-        const int64_t nl = f->hs.out_used;
+        /* gather the per-right-hand-side regions into the dense (rhs, position) slab of the ABI */
         xl = (int32_t *) malloc((size_t) ne * 4);
-        xlimbs = (uint64_t *) malloc((size_t)(nl > 0 ? nl : 1) * 8);
-        if (!xl || !xlimbs) rc = SLIP_HIP_OUT_OF_MEMORY;
+        hooff = (int64_t *) malloc((size_t) ne * 8);
+        raw = (uint64_t *) malloc((size_t)(ostride * nrhs) * 8);
+        if (!xl || !hooff || !raw) rc = SLIP_HIP_OUT_OF_MEMORY;
         if (!rc && (hipMemcpy(xl, dolen, (size_t) ne * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-                    (nl > 0 && hipMemcpy(xlimbs, dol, (size_t) nl * 8, hipMemcpyDeviceToHost) != hipSuccess)))
+                    hipMemcpy(hooff, dooff, (size_t) ne * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(raw, dol, (size_t)(ostride * nrhs) * 8, hipMemcpyDeviceToHost) != hipSuccess))
             rc = SLIP_HIP_DEVICE_ERROR;
         if (!rc) {
-            /* digits -> limbs; entries were laid out in (rhs, position) order, so the slab is already dense */
-            for (int64_t t = 0; t < ne; t++) { const int32_t d = xl[t], l = ((d < 0 ? -d : d) + 1) >> 1; xl[t] = d < 0 ? -l : l; }
-            *xlen_out = xl; *xlimbs_out = xlimbs; *xnl_out = nl;
-            xl = NULL; xlimbs = NULL;
+            int64_t nl = 0;
+            for (int64_t t = 0; t < ne; t++) { const int32_t d = xl[t]; nl += ((d < 0 ? -d : d) + 1) >> 1; }
+            xlimbs = (uint64_t *) malloc((size_t)(nl > 0 ? nl : 1) * 8);
+            if (!xlimbs) rc = SLIP_HIP_OUT_OF_MEMORY;
+            else {
+                int64_t at = 0;
+                for (int64_t t = 0; t < ne; t++) {
+                    const int32_t d = xl[t], l = ((d < 0 ? -d : d) + 1) >> 1;
+                    if (l) memcpy(xlimbs + at, raw + hooff[t], (size_t) l * 8);
+                    at += l;
+                    xl[t] = d < 0 ? -l : l;
+                }
+                *xlen_out = xl; *xlimbs_out = xlimbs; *xnl_out = nl;
+                xl = NULL; xlimbs = NULL;
+            }
         }
     }
-    free(xl); free(xlimbs); free(hlen); free(hoff);
-    hipFree(dblen); hipFree(dboff); hipFree(dbl); hipFree(dolen); hipFree(dooff); hipFree(dol);
+    free(xl); free(xlimbs); free(hlen); free(hoff); free(hdone); free(raw); free(hooff);
+    hipFree(dblen); hipFree(dboff); hipFree(dbl); hipFree(dolen); hipFree(dooff); hipFree(dol); hipFree(ddone);
     return rc;
 }
 
 extern "C" double slip_hip_factor_solve_ms(const slip_hip_factor *f) { return f ? f->solve_ms : 0.0; }
 
 /* diagnostic: per-phase shader cycles of the last run (zeros unless built with -DSLIP_PROFILE_PHASES) */
-extern "C" int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out12)
+extern "C" int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out24)
 {
-    if (!f || !out12) return SLIP_HIP_INCORRECT_INPUT;
-    for (int i = 0; i < 20; i++) out12[i] = f->hs.prof[i];
+    if (!f || !out24) return SLIP_HIP_INCORRECT_INPUT;
+    for (int i = 0; i < 24; i++) out24[i] = f->hs.prof[i];
     return SLIP_HIP_OK;
 }
 
@@ -765,29 +893,48 @@ extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)
 {
     if (!f || !o) return SLIP_HIP_INCORRECT_INPUT;
     const SlipState *h = &f->hs;
-    o->n = f->n; o->K = h->k_next; o->status = f->last_status; o->window_end = f->window_end;
-    o->lnz = h->Lnz; o->unz = h->Unz; o->l_limbs = h->Lnl_exact; o->u_limbs = h->Unl;
+    o->n = f->n; o->K = h->F; o->status = f->last_status; o->window_end = f->window_end;
+    o->lnz = h->Lnz; o->unz = h->Unz; o->l_limbs = h->Lnl_exact; o->u_limbs = h->Unl_exact;
     o->n_upd = (int64_t) h->c_upd; o->b_read = (int64_t) h->c_read; o->b_write = (int64_t) h->c_write;
     o->n_src = (int64_t) h->c_src; o->l_streamed = (int64_t) h->c_streamed;
     o->max_limbs = (int64_t)((h->c_maxdig + 1) / 2);
     o->kernel_ms = f->kernel_ms; o->launches = f->launches; o->xcap_digits = f->P.xcap;
+    o->limb_macs = (int64_t) h->c_macs; o->workers = f->nworkers; o->waves = f->waves; o->lds_bytes = f->lds_words * 4;
     return SLIP_HIP_OK;
 }
 
-/* signed digit counts of stored entries -> signed 64-bit limb counts */
-static int fetch_lens(int32_t *dst, const SlipEnt *dev, int64_t cnt)
+/* entry records -> signed 64-bit limb counts, and the limbs gathered entry by entry into the back-to-back layout
+ * of the ABI (slots of rows multiplied straight into the slab may leave unused limbs behind them) */
+static int fetch_factor(int32_t *len_out, uint64_t *limbs_out, const SlipEnt *dev_ent, const uint64_t *dev_limbs, int64_t nz, int64_t nl_alloc)
 {
-    if (cnt <= 0) return 0;
-    SlipEnt *tmp = (SlipEnt *) malloc((size_t) cnt * sizeof(SlipEnt));
-    if (!tmp) return SLIP_HIP_OUT_OF_MEMORY;
-    if (hipMemcpy(tmp, dev, (size_t) cnt * sizeof(SlipEnt), hipMemcpyDeviceToHost) != hipSuccess) { free(tmp); return SLIP_HIP_DEVICE_ERROR; }
-    for (int64_t t = 0; t < cnt; t++) {
-        int32_t d = tmp[t].len, a = d < 0 ? -d : d;
-        a = (a + 1) >> 1;
-        dst[t] = d < 0 ? -a : a;
+    if (nz <= 0) return 0;
+    SlipEnt *ent = (SlipEnt *) malloc((size_t) nz * sizeof(SlipEnt));
+    if (!ent) return SLIP_HIP_OUT_OF_MEMORY;
+    if (hipMemcpy(ent, dev_ent, (size_t) nz * sizeof(SlipEnt), hipMemcpyDeviceToHost) != hipSuccess) { free(ent); return SLIP_HIP_DEVICE_ERROR; }
+    if (len_out)
+        for (int64_t t = 0; t < nz; t++) {
+            int32_t d = ent[t].len, a = d < 0 ? -d : d;
+            a = (a + 1) >> 1;
+            len_out[t] = d < 0 ? -a : a;
+        }
+    int rc = 0;
+    if (limbs_out && nl_alloc > 0) {
+        uint64_t *raw = (uint64_t *) malloc((size_t) nl_alloc * 8);
+        if (!raw) rc = SLIP_HIP_OUT_OF_MEMORY;
+        else if (hipMemcpy(raw, dev_limbs, (size_t) nl_alloc * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+        else {
+            int64_t o = 0;
+            for (int64_t t = 0; t < nz; t++) {
+                const int32_t d = ent[t].len;
+                const int64_t l = ((d < 0 ? -d : d) + 1) >> 1;
+                if (l) memcpy(limbs_out + o, raw + ent[t].off, (size_t) l * 8);
+                o += l;
+            }
+        }
+        free(raw);
     }
-    free(tmp);
-    return 0;
+    free(ent);
+    return rc;
 }
 
 extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
@@ -799,32 +946,14 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
     if (!f) return SLIP_HIP_INCORRECT_INPUT;
     const SlipParams *P = &f->P;
     const SlipState *h = &f->hs;
-    const int32_t K = h->k_next;
+    const int32_t K = h->F;
     int e;
     if (Lp) CK(hipMemcpy(Lp, P->Lp, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost));
     if (Up) CK(hipMemcpy(Up, P->Up, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost));
     if (Li && h->Lnz) CK(hipMemcpy(Li, P->Li, (size_t) h->Lnz * 4, hipMemcpyDeviceToHost));
     if (Ui && h->Unz) CK(hipMemcpy(Ui, P->Ui, (size_t) h->Unz * 4, hipMemcpyDeviceToHost));
-    if (Llen && (e = fetch_lens(Llen, P->Le, h->Lnz))) return e;
-    if (Ulen && (e = fetch_lens(Ulen, P->Ue, h->Unz))) return e;
-    if (Llimbs && h->Lnl) {
-        /* rows multiplied straight into the slab may leave one unused limb behind them: the slab is
-         * gathered entry by entry into the back-to-back layout of the ABI */
-        SlipEnt *le = (SlipEnt *) malloc((size_t)(h->Lnz ? h->Lnz : 1) * sizeof(SlipEnt));
-        uint64_t *raw = (uint64_t *) malloc((size_t) h->Lnl * 8);
-        if (!le || !raw) { free(le); free(raw); return SLIP_HIP_OUT_OF_MEMORY; }
-        if (hipMemcpy(le, P->Le, (size_t) h->Lnz * sizeof(SlipEnt), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(raw, P->Llimbs, (size_t) h->Lnl * 8, hipMemcpyDeviceToHost) != hipSuccess) { free(le); free(raw); return SLIP_HIP_DEVICE_ERROR; }
-        int64_t o = 0;
-        for (int64_t t = 0; t < h->Lnz; t++) {
-            const int32_t d = le[t].len;
-            const int64_t l = ((d < 0 ? -d : d) + 1) >> 1;
-            memcpy(Llimbs + o, raw + le[t].off, (size_t) l * 8);
-            o += l;
-        }
-        free(le); free(raw);
-    }
-    if (Ulimbs && h->Unl) CK(hipMemcpy(Ulimbs, P->Ulimbs, (size_t) h->Unl * 8, hipMemcpyDeviceToHost));
+    if ((Llen || Llimbs) && (e = fetch_factor(Llen, Llimbs, P->Le, P->Llimbs, h->Lnz, h->Lnl))) return e;
+    if ((Ulen || Ulimbs) && (e = fetch_factor(Ulen, Ulimbs, P->Ue, P->Ulimbs, h->Unz, h->Unl))) return e;
     if (pinv) CK(hipMemcpy(pinv, P->pinv, (size_t) f->n * 4, hipMemcpyDeviceToHost));
     if ((rholen || rholimbs) && K > 0) {
         /* the pivots live in the L slab: gather them through the pivot records */
@@ -875,7 +1004,7 @@ extern "C" int slip_hip_wave_op_test(int32_t op, int32_t nops, int32_t la, int32
         else if (op == 2) wb_addsub(O, A, la, B, lb, W, 1);
         else if (op == 3) wb_inv_extend(O, 0, W, A, la, s0, s1);
         else slip_reg_op_test(op, A, la, B, lb, W, O, s0);
-    });
+    }, 256 * 1024, 1);
 #endif
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(out, dout, (size_t) nops * W * 4, hipMemcpyDeviceToHost));

@@ -64,8 +64,26 @@ static inline void slip_agent_acquire(void) {}
 static inline int32_t slip_agent_load_i32(const int32_t *p) { return *(volatile const int32_t *) p; }
 static inline void slip_agent_store_i32(int32_t *p, int32_t v) { *(volatile int32_t *) p = v; }
 static inline int32_t slip_agent_add_i32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
-static inline void slip_sleep(void) {}
+static inline void slip_sleep(void) { emu::spin_yield(); }       /* a spin-wait iteration: let the other workgroups run */
+static inline void slip_sleep_short(void) { emu::spin_yield(); }
 static inline unsigned long long slip_clock(void) { return 0; }
+/* data other workgroups write / read during a launch (sc1 on the device; plain here: the emulator is sequentially consistent) */
+static inline uint32_t slip_ld_u32(const uint32_t *p) { return *(volatile const uint32_t *) p; }
+static inline int32_t  slip_ld_i32(const int32_t *p)  { return *(volatile const int32_t *) p; }
+static inline uint64_t slip_ld_u64(const uint64_t *p) { return *(volatile const uint64_t *) p; }
+static inline int64_t  slip_ld_i64(const int64_t *p)  { return *(volatile const int64_t *) p; }
+static inline void slip_st_u32(uint32_t *p, uint32_t v) { *(volatile uint32_t *) p = v; }
+static inline void slip_st_i32(int32_t *p, int32_t v)   { *(volatile int32_t *) p = v; }
+static inline void slip_st_u64(uint64_t *p, uint64_t v) { *(volatile uint64_t *) p = v; }
+static inline void slip_st_i64(int64_t *p, int64_t v)   { *(volatile int64_t *) p = v; }
+/* this workgroup's own global data (plain global accesses on the device) */
+static inline uint32_t slip_gld_u32(const uint32_t *p) { return *p; }
+static inline void slip_gst_u32(uint32_t *p, uint32_t v) { *p = v; }
+static inline int32_t slip_agent_max_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v > o) *p = v; return o; }
+static inline int32_t slip_agent_cas_i32(int32_t *p, int32_t expect, int32_t v) { int32_t o = *p; if (o == expect) *p = v; return o; }
+static inline int64_t slip_agent_min_i64(int64_t *p, int64_t v) { int64_t o = *p; if (v < o) *p = v; return o; }
+static inline unsigned long long slip_agent_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+static inline unsigned long long slip_agent_max_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 static inline int slip_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 static inline int slip_ctz32(uint32_t v) { return v ? __builtin_ctz(v) : 32; }
 static inline int slip_clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
@@ -160,6 +178,35 @@ SLIP_DEV int32_t slip_agent_load_i32(const int32_t *p) { return __hip_atomic_fet
 SLIP_DEV void slip_agent_store_i32(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 SLIP_DEV int32_t slip_agent_add_i32(int32_t *p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 SLIP_DEV void slip_sleep(void) { __builtin_amdgcn_s_sleep(32); }
+SLIP_DEV void slip_sleep_short(void) { __builtin_amdgcn_s_sleep(2); }
+/* Data other workgroups write / read during a launch: relaxed agent-scope accesses through GLOBAL pointers
+ * (global_load/store ... sc1: the load bypasses this CU's L1, the store is written through; never flat_,
+ * cdna_hip_programming.md Guideline 16).  The writer drains (vmcnt(0)) before it raises the flag that
+ * publishes the data; the reader needs no acquire fence because EVERY load of such data is one of these. */
+typedef __attribute__((address_space(1))) uint32_t slip_gu32;
+typedef __attribute__((address_space(1))) int32_t  slip_gi32;
+typedef __attribute__((address_space(1))) uint64_t slip_gu64;
+typedef __attribute__((address_space(1))) int64_t  slip_gi64;
+SLIP_DEV uint32_t slip_ld_u32(const uint32_t *p) { return __hip_atomic_load((slip_gu32 *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV int32_t  slip_ld_i32(const int32_t *p)  { return __hip_atomic_load((slip_gi32 *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV uint64_t slip_ld_u64(const uint64_t *p) { return __hip_atomic_load((slip_gu64 *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV int64_t  slip_ld_i64(const int64_t *p)  { return __hip_atomic_load((slip_gi64 *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV void slip_st_u32(uint32_t *p, uint32_t v) { __hip_atomic_store((slip_gu32 *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV void slip_st_i32(int32_t *p, int32_t v)   { __hip_atomic_store((slip_gi32 *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV void slip_st_u64(uint64_t *p, uint64_t v) { __hip_atomic_store((slip_gu64 *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV void slip_st_i64(int64_t *p, int64_t v)   { __hip_atomic_store((slip_gi64 *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+/* this workgroup's own global data: plain accesses, but through global (not flat) instructions */
+SLIP_DEV uint32_t slip_gld_u32(const uint32_t *p) { return *(const slip_gu32 *) p; }
+SLIP_DEV void slip_gst_u32(uint32_t *p, uint32_t v) { *(slip_gu32 *) p = v; }
+SLIP_DEV int32_t slip_agent_max_i32(int32_t *p, int32_t v) { return __hip_atomic_fetch_max((slip_gi32 *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV int32_t slip_agent_cas_i32(int32_t *p, int32_t expect, int32_t v)      /* returns the value found */
+{
+    __hip_atomic_compare_exchange_strong((slip_gi32 *) p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expect;
+}
+SLIP_DEV int64_t slip_agent_min_i64(int64_t *p, int64_t v) { return __hip_atomic_fetch_min((slip_gi64 *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV unsigned long long slip_agent_add_u64(unsigned long long *p, unsigned long long v) { return __hip_atomic_fetch_add((slip_gu64 *) p, (uint64_t) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SLIP_DEV unsigned long long slip_agent_max_u64(unsigned long long *p, unsigned long long v) { return __hip_atomic_fetch_max((slip_gu64 *) p, (uint64_t) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 SLIP_DEV unsigned long long slip_clock(void) { return (unsigned long long) clock64(); }
 SLIP_DEV int slip_clz32(uint32_t v) { return __clz((int) v); }
 SLIP_DEV int slip_ctz32(uint32_t v) { return v ? __ffs((int) v) - 1 : 32; }

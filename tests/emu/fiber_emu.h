@@ -1,10 +1,15 @@
-/* fiber_emu.h -- lane-by-lane CPU emulation of a wave64 workgroup (TEST ONLY).
+/* fiber_emu.h -- lane-by-lane CPU emulation of a grid of wave64 workgroups (TEST ONLY).
  *
- * Every GPU thread becomes a ucontext fiber; one workgroup runs at a time and
- * its fibers are switched cooperatively at the cross-lane operations
- * (shfl / ballot / block barrier).  All 64 lanes of a wave must reach the
- * same call site (checked), which is exactly the wave-uniform control flow
- * the real kernel needs.  Nothing here is part of the product.
+ * Every GPU thread becomes a ucontext fiber.  All workgroups of a launch are alive at the same
+ * time and their fibers are switched cooperatively at the cross-lane operations (shfl / ballot /
+ * block barrier) and at the spin-wait points of the inter-workgroup protocols (emu::spin_yield),
+ * so a persistent multi-workgroup kernel (column workers that wait for each other's commits) runs
+ * to completion on one OS thread.  The order in which workgroups get the processor is a seeded
+ * pseudo-random interleaving (emu::set_seed), which lets the tests shake the hand-off logic.
+ * All 64 lanes of a wave must reach the same call site (checked): exactly the wave-uniform
+ * control flow the real kernel needs.  Memory is sequentially consistent here: cache-visibility
+ * bugs (missing sc1 / release) are NOT found by this emulator, logic and ordering bugs are.
+ * Nothing here is part of the product.
  */
 #ifndef FIBER_EMU_H
 #define FIBER_EMU_H
@@ -15,6 +20,12 @@
 #include <functional>
 #include <vector>
 
+#if defined(__SANITIZE_ADDRESS__)
+extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const void **bottom_old, size_t *size_old);
+#define EMU_ASAN 1
+#endif
+
 namespace emu {
 
 struct WaveCtx {
@@ -24,31 +35,59 @@ struct WaveCtx {
     unsigned gen = 0;
 };
 
-struct State {
-    int nthreads = 0, nblocks = 0, block = 0, cur = 0;
+struct Block {
     std::vector<ucontext_t> ctx;
-    std::vector<char *> stacks;
     std::vector<char> done;
     std::vector<WaveCtx> waves;
-    ucontext_t sched;
-    int bar_arrived = 0; unsigned bar_gen = 0; int bar_site = 0;
     std::vector<int> last_site;          /* per thread: line of the cross-lane op it last entered (-line: barrier) */
+    int bar_arrived = 0; unsigned bar_gen = 0; int bar_site = 0;
+    int remaining = 0;
+};
+
+struct State {
+    int nthreads = 0, nblocks = 0, block = 0, cur = 0;
+    std::vector<Block> blocks;
+    std::vector<char *> stacks;          /* nblocks * nthreads stacks, reused across launches */
+    size_t stack_bytes = 0;
+    ucontext_t sched;
+    const void *sched_stack = nullptr; size_t sched_stack_size = 0;
     unsigned long progress = 0;          /* bumped whenever a collective / barrier completes or a thread ends */
+    unsigned long long rng = 0x9E3779B97F4A7C15ull;
     std::function<void()> body;
 };
 
 inline State &S() { static State s; return s; }
+
+inline void set_seed(unsigned long long seed) { S().rng = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull; }
+inline unsigned rnd() { State &s = S(); s.rng ^= s.rng << 13; s.rng ^= s.rng >> 7; s.rng ^= s.rng << 17; return (unsigned)(s.rng >> 32); }
 
 inline int tid() { return S().cur; }
 inline int nthreads() { return S().nthreads; }
 inline int block() { return S().block; }
 inline int nblocks() { return S().nblocks; }
 
-inline void yield_() { State &s = S(); swapcontext(&s.ctx[s.cur], &s.sched); }
+inline void yield_()
+{
+    State &s = S();
+    Block &b = s.blocks[s.block];
+    const int me = s.cur, myb = s.block;
+#ifdef EMU_ASAN
+    void *fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, s.sched_stack, s.sched_stack_size);
+#endif
+    swapcontext(&b.ctx[me], &s.sched);
+#ifdef EMU_ASAN
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+    (void) me; (void) myb;
+}
+
+/* a spin-wait iteration of an inter-workgroup protocol: let every other fiber run */
+inline void spin_yield() { yield_(); }
 
 [[noreturn]] inline void die(const char *msg, int a, int b)
 {
-    fprintf(stderr, "fiber_emu: %s (%d vs %d) at thread %d\n", msg, a, b, S().cur);
+    fprintf(stderr, "fiber_emu: %s (%d vs %d) at block %d thread %d\n", msg, a, b, S().block, S().cur);
     abort();
 }
 
@@ -56,10 +95,11 @@ inline void yield_() { State &s = S(); swapcontext(&s.ctx[s.cur], &s.sched); }
 inline const uint64_t *collective(uint64_t v, int site)
 {
     State &s = S();
+    Block &b = s.blocks[s.block];
     int lane = s.cur & 63;
-    WaveCtx &w = s.waves[s.cur >> 6];
+    WaveCtx &w = b.waves[s.cur >> 6];
     unsigned g = w.gen;
-    s.last_site[s.cur] = site;
+    b.last_site[s.cur] = site;
     w.vals[lane] = v; w.site[lane] = site;
     if (++w.arrived == 64) {
         s.progress++;
@@ -91,69 +131,109 @@ inline uint64_t shfl(uint64_t v, int src, int site)
 inline void block_sync(int site)
 {
     State &s = S();
-    unsigned g = s.bar_gen;
-    s.last_site[s.cur] = -site;
-    if (s.bar_arrived == 0) s.bar_site = site;
-    else if (s.bar_site != site) die("threads at different barriers, lines", s.bar_site, site);
-    if (++s.bar_arrived == s.nthreads) { s.bar_arrived = 0; s.bar_gen++; s.progress++; }
-    else while (s.bar_gen == g) yield_();
+    Block &b = s.blocks[s.block];
+    unsigned g = b.bar_gen;
+    b.last_site[s.cur] = -site;
+    if (b.bar_arrived == 0) b.bar_site = site;
+    else if (b.bar_site != site) die("threads at different barriers, lines", b.bar_site, site);
+    if (++b.bar_arrived == s.nthreads) { b.bar_arrived = 0; b.bar_gen++; s.progress++; }
+    else while (b.bar_gen == g) yield_();
 }
 
 inline void trampoline()
 {
     State &s = S();
+#ifdef EMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &s.sched_stack, &s.sched_stack_size);
+#endif
     s.body();
-    s.done[s.cur] = 1;
-    swapcontext(&s.ctx[s.cur], &s.sched);
+    s.blocks[s.block].done[s.cur] = 1;
+#ifdef EMU_ASAN
+    void *fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, s.sched_stack, s.sched_stack_size);   /* this fiber never comes back */
+#endif
+    swapcontext(&s.blocks[s.block].ctx[s.cur], &s.sched);
 }
 
-/* run `body` as a grid of nblocks x nthreads (nthreads a multiple of 64) */
-inline void launch(int nblocks, int nthreads_, std::function<void()> body, size_t stack_bytes = 256 * 1024)
+inline void report_deadlock()
+{
+    State &s = S();
+    fprintf(stderr, "fiber_emu: DEADLOCK -- no collective completed for many scheduler passes; threads wait at "
+                    "(line, negative = block barrier, 0 = spin):\n");
+    for (int b = 0; b < s.nblocks; b++) {
+        Block &B = s.blocks[b];
+        for (int t = 0; t < s.nthreads; t++)
+            if (!B.done[t] && (t % 64 == 0 || B.last_site[t] != B.last_site[t - 1]))
+                fprintf(stderr, "  block %d thread %d.. : %d\n", b, t, B.last_site[t]);
+    }
+    abort();
+}
+
+/* run `body` as a grid of nblocks x nthreads (nthreads a multiple of 64); all blocks are alive together.
+ * sequential != 0: block after block (a grid of independent workgroups; cheaper, deterministic). */
+inline void launch(int nblocks, int nthreads_, std::function<void()> body, size_t stack_bytes = 256 * 1024, int sequential = 0)
 {
     State &s = S();
     if (nthreads_ % 64) die("block size must be a multiple of 64", nthreads_, 64);
     s.nthreads = nthreads_; s.nblocks = nblocks; s.body = body;
-    s.ctx.resize(nthreads_); s.done.assign(nthreads_, 0); s.last_site.assign(nthreads_, 0);
-    s.waves.assign(nthreads_ / 64, WaveCtx());
-    if ((int) s.stacks.size() < nthreads_) {
-        size_t old = s.stacks.size();
-        s.stacks.resize(nthreads_);
-        for (size_t i = old; i < (size_t) nthreads_; i++) s.stacks[i] = (char *) malloc(stack_bytes);
-    }
-    for (int b = 0; b < nblocks; b++) {
-        s.block = b; s.bar_arrived = 0;
-        for (auto &w : s.waves) { w.arrived = 0; }
+    if (s.stack_bytes != stack_bytes) { for (char *p : s.stacks) free(p); s.stacks.clear(); s.stack_bytes = stack_bytes; }
+    const size_t live_blocks = sequential ? 1 : (size_t) nblocks;
+    const size_t need = live_blocks * (size_t) nthreads_;
+    while (s.stacks.size() < need) s.stacks.push_back((char *) malloc(stack_bytes));
+    s.blocks.assign(nblocks, Block());
+    auto arm = [&](int b) {
+        Block &B = s.blocks[b];
+        B.ctx.resize(nthreads_); B.done.assign(nthreads_, 0); B.last_site.assign(nthreads_, 0);
+        B.waves.assign(nthreads_ / 64, WaveCtx());
+        B.remaining = nthreads_;
         for (int t = 0; t < nthreads_; t++) {
-            getcontext(&s.ctx[t]);
-            s.ctx[t].uc_stack.ss_sp = s.stacks[t];
-            s.ctx[t].uc_stack.ss_size = stack_bytes;
-            s.ctx[t].uc_link = &s.sched;
-            makecontext(&s.ctx[t], (void (*)()) trampoline, 0);
-            s.done[t] = 0;
+            getcontext(&B.ctx[t]);
+            B.ctx[t].uc_stack.ss_sp = s.stacks[(sequential ? 0 : (size_t) b * nthreads_) + t];
+            B.ctx[t].uc_stack.ss_size = stack_bytes;
+            B.ctx[t].uc_link = &s.sched;
+            makecontext(&B.ctx[t], (void (*)()) trampoline, 0);
         }
-        int remaining = nthreads_;
-        unsigned long seen = s.progress; int idle = 0;
-        while (remaining > 0) {
-            int progressed = 0;
-            /* deadlock detector: whole passes over the fibers without any collective completing */
-            if (s.progress != seen) { seen = s.progress; idle = 0; }
-            else if (++idle > 4) {
-                fprintf(stderr, "fiber_emu: DEADLOCK in block %d -- threads wait at different cross-lane ops "
-                                "(line, negative = block barrier):\n", b);
-                for (int t = 0; t < nthreads_; t++)
-                    if (!s.done[t] && (t % 64 == 0 || s.last_site[t] != s.last_site[t - 1]))
-                        fprintf(stderr, "  thread %d.. : %d\n", t, s.last_site[t]);
-                abort();
-            }
-            for (int t = 0; t < nthreads_; t++) {
-                if (s.done[t]) continue;
-                s.cur = t;
-                swapcontext(&s.sched, &s.ctx[t]);
-                progressed = 1;
-                if (s.done[t]) { remaining--; s.progress++; }
-            }
-            if (!progressed) break;
+    };
+    auto run_pass = [&](int b) {                /* one pass over the fibers of block b */
+        Block &B = s.blocks[b];
+        for (int t = 0; t < nthreads_ && B.remaining > 0; t++) {
+            if (B.done[t]) continue;
+            s.block = b; s.cur = t;
+#ifdef EMU_ASAN
+            void *fake = nullptr;
+            __sanitizer_start_switch_fiber(&fake, B.ctx[t].uc_stack.ss_sp, B.ctx[t].uc_stack.ss_size);
+#endif
+            swapcontext(&s.sched, &B.ctx[t]);
+#ifdef EMU_ASAN
+            __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+            if (B.done[t]) { B.remaining--; s.progress++; }
         }
+    };
+    if (sequential) {
+        for (int b = 0; b < nblocks; b++) {
+            arm(b);
+            unsigned long seen = s.progress; int idle = 0;
+            while (s.blocks[b].remaining > 0) {
+                if (s.progress != seen) { seen = s.progress; idle = 0; }
+                else if (++idle > 64) report_deadlock();
+                run_pass(b);
+            }
+        }
+        return;
+    }
+    for (int b = 0; b < nblocks; b++) arm(b);
+    int live = nblocks;
+    unsigned long seen = s.progress; long idle = 0;
+    while (live > 0) {
+        if (s.progress != seen) { seen = s.progress; idle = 0; }
+        else if (++idle > 200000) report_deadlock();
+        /* pick a live block pseudo-randomly and give it a random number of passes */
+        int b = (int)(rnd() % (unsigned) nblocks);
+        while (s.blocks[b].remaining == 0) b = (b + 1) % nblocks;
+        const int passes = 1 + (int)(rnd() % 4u);
+        for (int p = 0; p < passes && s.blocks[b].remaining > 0; p++) run_pass(b);
+        if (s.blocks[b].remaining == 0) live--;
     }
 }
 

@@ -19,26 +19,38 @@ def emu_lib():
     return EMU
 
 
-@pytest.mark.parametrize("name,waves,fork_min", [("test_mat", 2, 0), ("test_mat_p1", 1, 0), ("test_mat_p2", 4, 0),
-                                                 ("test_mat_p4tol", 2, 0), ("test_mat_p5", 2, 1), ("test_mat_tol01", 2, 0),
-                                                 ("test_mat_noord", 16, 0), ("gen_n40", 2, 0), ("gen_n40", 4, 1)])
-def test_emulated_kernel_matches_reference(emu_lib, name, waves, fork_min):
+def set_seed(emu_lib, seed):
+    """the interleaving of the emulated workgroups is a seeded pseudo-random schedule (tests/emu/fiber_emu.h)"""
+    import ctypes
+    lib = ctypes.CDLL(emu_lib)
+    lib.slip_emu_set_seed.argtypes = [ctypes.c_ulonglong]
+    lib.slip_emu_set_seed(seed)
+
+
+@pytest.mark.parametrize("name,waves,workers", [("test_mat", 2, 1), ("test_mat", 1, 3), ("test_mat_p1", 1, 4), ("test_mat_p2", 4, 2),
+                                                ("test_mat_p4tol", 2, 3), ("test_mat_p5", 2, 5), ("test_mat_tol01", 2, 2),
+                                                ("test_mat_noord", 16, 1), ("test_mat_amd", 1, 10), ("gen_n40", 2, 1), ("gen_n40", 1, 6)])
+def test_emulated_kernel_matches_reference(emu_lib, name, waves, workers):
+    """the column-worker pipeline on `workers` concurrently emulated workgroups, several interleavings"""
     import slip_lu_amd as sl
     entry, fix = load_case(name)
-    res = sl.factorize(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"],
-                       pivot=entry["pivot"], tol=entry["tol"], kmax=entry["kmax"], limb_cap=entry["cap"],
-                       waves=waves, fork_min=fork_min, lib_path=emu_lib)   # fork_min: batch hand-off path, no helpers
-    check_against_golden(entry, fix, res)
+    for seed in (1, 2, 3):
+        set_seed(emu_lib, seed)
+        res = sl.factorize(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"],
+                           pivot=entry["pivot"], tol=entry["tol"], kmax=entry["kmax"], limb_cap=entry["cap"],
+                           waves=waves, workers=workers, lib_path=emu_lib)
+        check_against_golden(entry, fix, res)
 
 
-@pytest.mark.parametrize("name,waves,fork_min,nrhs", [("solve_test_mat", 2, 0, 1), ("solve_gen_n40", 2, 0, 2),
-                                                      ("solve_gen_n40", 4, 1, 1)])
-def test_emulated_solve_matches_reference(emu_lib, name, waves, fork_min, nrhs):
-    """forward / back substitution of the kernel source (slip_solve_rhs) against orc_solve and the reference's x"""
+@pytest.mark.parametrize("name,waves,workers,nrhs", [("solve_test_mat", 2, 1, 1), ("solve_gen_n40", 2, 2, 2),
+                                                     ("solve_gen_n40", 1, 3, 3)])
+def test_emulated_solve_matches_reference(emu_lib, name, waves, workers, nrhs):
+    """forward / back substitution of the kernel source (slip_solve_rhs) against orc_solve and the reference's x;
+    the right-hand sides are spread over the workers"""
     import json
     from conftest import GOLDEN, check_solve
     case = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "solve_index.json")))}[name]
-    check_solve(case, lib_path=emu_lib, nrhs=nrhs, waves=waves, fork_min=fork_min)
+    check_solve(case, lib_path=emu_lib, nrhs=nrhs, waves=waves, workers=workers)
 
 
 def test_emulated_solve_zero_and_unit_rhs(emu_lib):

@@ -59,6 +59,7 @@ def test_gpu_matches_oracle_on_fresh_seeds():
             for k in ("pinv", "Lp", "Li", "Llen", "Llimbs", "Up", "Ui", "Ulen", "Ulimbs", "rholen", "rholimbs"):
                 assert np.array_equal(np.asarray(got[k]).astype(np.int64), np.asarray(ref[k]).astype(np.int64)), (seed, pivot, k)
             assert list(got["counters"][:6]) == list(ref["counters"][:6])
+            assert int(got["counters"][7]) == int(ref["counters"][7])          # limb-MAC counter
 
 
 def test_gpu_multilimb_inputs_and_duplicates():
@@ -171,13 +172,47 @@ def test_gpu_subtree_farm_law():
     T.check_farm(gpu_factor, sizes=(40, 25, 60), seed=5)
 
 
-@pytest.mark.parametrize("name,kw", [("prob159", dict(fork_min=1, helpers=7)), ("gen_n300", dict(fork_min=1, helpers=0)),
-                                     ("rl5934", dict(fork_min=2, helpers=63)), ("C4_n100k_c64", dict(fork_min=1))])
-def test_gpu_every_batch_kind_through_the_handoff(name, kw):
-    """fork_min this low sends every queue -- IPGE updates (kind 1), history rows (2) and the one-limb rows multiplied
-    straight into the L slab (kind 3, threshold 10*fork_min) -- through the publish/acquire hand-off (or, without
-    helpers, through the published-batch path on the master); results must not depend on who did the work."""
+@pytest.mark.parametrize("name,kw", [("prob159", dict(workers=1)), ("prob159", dict(workers=2, waves=1)), ("gen_n300", dict(workers=7, waves=2)),
+                                     ("rl5934", dict(workers=64)), ("rl5934", dict(workers=4096, waves=8)),
+                                     ("C4_n100k_c64", dict(workers=3)), ("C4_n100k_c64", dict(workers=1000)),
+                                     ("NSR8K_w600", dict(workers=2048, waves=2)), ("10teams", dict(workers=177))])
+def test_gpu_worker_count_independent(name, kw):
+    """Every column goes through the worker pipeline; the factors must not depend on how many workers run ahead of
+    the commit frontier -- one worker (no look-ahead at all), a handful, one per column, or far more workgroups than
+    the device can hold at once (a workgroup that is not resident holds no column ticket, so nothing waits for it)."""
     entry, fix = load_case(name)
     res = _run(entry, fix, **kw)
     assert res["status"] == entry["status"]
     check_against_golden(entry, fix, res)
+
+
+def test_gpu_limb_mac_counter_matches_oracle():
+    """the ALU-roofline counter, sum over the IPGE updates of l(L_m) l(x_j) + l(x_i) l(rho_jn) in 64-bit
+    limbs, counted by the device == the CPU restatement's ORC_LIMB_MACS (12 440 261 on the headline window)."""
+    entry, fix = load_case("C4_n100k_c64")
+    res = _run(entry, fix)
+    assert res["info"]["limb_macs"] == 12440261
+    for name in ("prob159", "10teams", "gen_n300"):
+        entry, fix = load_case(name)
+        res = _run(entry, fix)
+        ref = oracle_lib.factorize(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"],
+                                   pivot=entry["pivot"], kmax=entry["kmax"])
+        assert res["info"]["limb_macs"] == int(ref["counters"][7]), name
+
+
+def test_gpu_repeated_runs_under_load_are_identical():
+    """The hand-offs between workers (commit frontier, ready frontier, inverse cache) under uneven load: the same
+    factorisation twenty times on a handle, different worker counts interleaved, always the reference's bytes."""
+    import slip_lu_amd as sl
+    import slabfile
+    entry, fix = load_case("rl5934")
+    handles = [sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], workers=w, waves=wv)
+               for w, wv in ((0, 0), (5, 2), (97, 1))]
+    try:
+        for rep in range(7):
+            for f in handles:
+                f.reset(); f.run()
+                assert slabfile.factor_digest(f.download()) == entry["digest"], rep
+    finally:
+        for f in handles:
+            f.close()

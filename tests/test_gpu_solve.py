@@ -17,9 +17,10 @@ CASES = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "solve_index.
 
 @pytest.mark.parametrize("name,nrhs,kw", [
     ("solve_test_mat", 1, {}), ("solve_gen_n40", 3, {}), ("solve_10teams", 2, {}),
-    ("solve_gen_n40", 2, dict(helpers=0)),                      # master workgroup alone
-    ("solve_10teams", 1, dict(fork_min=1)),                     # every wave item through the helper hand-off
-    ("solve_gen_n40", 1, dict(waves=1)), ("solve_10teams", 1, dict(waves=4, helpers=3))])
+    ("solve_gen_n40", 2, dict(workers=1)),                      # one worker takes the right-hand sides in turn
+    ("solve_10teams", 16, {}),                                  # one worker per right-hand side
+    ("solve_10teams", 5, dict(workers=2, waves=8)),
+    ("solve_gen_n40", 1, dict(waves=1)), ("solve_10teams", 1, dict(waves=4, workers=3))])
 def test_gpu_solve_matches_reference(name, nrhs, kw):
     check_solve(CASES[name], nrhs=nrhs, **kw)
 
