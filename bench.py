@@ -12,12 +12,13 @@ region; every step starts from column 0 (device-side reset included in the timin
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path has no exploitable
-elimination-tree subtrees on this matrix class (multi-GPU), so ranks are
-independent replicas of the same workload -- weak scaling, no data-path collective; RCCL is
-used only for the barrier and the max-over-ranks of the step time.
+N > 1: one rank per GPU under torch.distributed.run (started here as a child process when the
+caller did not).  The path has no exploitable elimination-tree subtrees on this matrix class
+(multi-GPU), so ranks are independent replicas of the same workload -- weak scaling,
+no data-path collective; RCCL is used only for the barrier and the max-over-ranks of the step time.
 """
 import argparse
+import glob
 import json
 import os
 import subprocess
@@ -29,7 +30,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# integer side: a 64x64-bit limb multiply-accumulate is four 32x32->64 v_mad_u64_u32; that instruction issues at a
+# quarter of the 32-lanes-per-cycle VALU rate: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz / 4 digit-MACs per second
+DIGIT_MAC_PEAK = 256 * 4 * 32 * 2.4e9 / 4
 WORKLOAD = dict(n=100000, density=0.001, bits=16, seed=1, limb_cap=64, golden="C4_n100k_c64")
+SECONDARY = ("10teams", "prob159", "NSR8K_w600", "rl5934", "rail4284", "fome12", "NSR8K")
 
 
 def load_q(name):
@@ -37,13 +42,32 @@ def load_q(name):
     return slabfile.load(os.path.join(ROOT, "tests", "golden", name + ".slab.gz"))["q"]
 
 
+def relaunch_distributed(args):
+    """--gpus N > 1 without a torchrun environment: start one rank per GPU as a CHILD process (nothing in this
+    process has touched the GPU yet) and leave with its exit code."""
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_secondary:
+        cmd.append("--no-secondary")
+    return cmd
+
+
+def ref_driver_path():
+    p = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    return p if os.path.exists(p) else None
+
+
 def cpu_baseline(expect_K, expect_nnz):
     """The reference's own column loop on this host's cores (1 core: it is single-threaded),
     on the same window.  Prefers the compiled reference (oracle/_ref), else the C restatement."""
     w = WORKLOAD
-    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    drv = ref_driver_path()
     sample = f"same workload: columns [0,{expect_K}) of gen:{w['n']},{w['density']},{w['bits']},{w['seed']}"
-    if os.path.exists(drv):
+    if drv:
         try:
             import slabfile
             out = os.path.join("/tmp", f"slip_ref_{os.getpid()}.slab")
@@ -70,6 +94,80 @@ def cpu_baseline(expect_K, expect_nnz):
                 seconds=r["seconds"], sample=sample + " (CPU restatement oracle/ref_lu_oracle.c)")
 
 
+def write_triplet(path, fix, n):
+    """the reference's triplet text format (Demo/demos.c:245-331), 1-based"""
+    import numpy as np
+    Ap, Ai, Alen, Alimbs = fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"]
+    off = np.concatenate([[0], np.cumsum(np.abs(Alen))])
+    with open(path, "w") as f:
+        f.write(f"{n} {n} {len(Ai)}\n")
+        for j in range(n):
+            for p in range(int(Ap[j]), int(Ap[j + 1])):
+                v = 0
+                for t in range(abs(int(Alen[p]))):
+                    v |= int(Alimbs[off[p] + t]) << (64 * t)
+                if Alen[p] < 0:
+                    v = -v
+                f.write(f"{int(Ai[p]) + 1} {j + 1} {v}\n")
+
+
+def reference_seconds(name, entry, fix):
+    """(factor seconds, solve seconds or None) of the compiled reference on THIS host for a secondary workload, or
+    (None, None) when oracle/_ref is not there.  Complete runs time SLIP_LU_factorize / SLIP_LU_solve themselves."""
+    drv = ref_driver_path()
+    if not drv:
+        return None, None
+    import slabfile
+    base = os.path.join("/tmp", f"slip_sec_{os.getpid()}_{name}")
+    trip, out, qf = base + ".txt", base + ".slab", os.path.join(ROOT, "tests", "golden", name + ".slab.gz")
+    try:
+        write_triplet(trip, fix, entry["n"])
+        # the golden holds q; ref_driver reads plain slab files
+        qplain = base + "_q.slab"
+        slabfile.save(qplain, {"q": fix["q"]})
+        if entry["kmax"] or entry["cap"]:
+            cmd = [drv, "window", "trip:" + trip, out, str(entry["kmax"]), str(entry["cap"]), str(entry["pivot"]), "1", str(entry["tol"]), "q:" + qplain]
+        else:
+            cmd = [drv, "solve", "trip:" + trip, out, str(entry["pivot"]), "1", str(entry["tol"]), "q:" + qplain]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        d = slabfile.load(out)
+        ts = float(d["solve_seconds"][0]) if "solve_seconds" in d else None
+        return float(d["timing"][0]), ts
+    except Exception as e:
+        print(f"[bench] reference timing of {name} unavailable: {e}", file=sys.stderr)
+        return None, None
+    finally:
+        for p in (trip, out, base + "_q.slab"):
+            if os.path.exists(p):
+                os.unlink(p)
+
+
+def profile_traffic(kernel_ms):
+    """HBM bytes per launch from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    passes, reduced by tools/profile_summary.py; counters cannot be read from inside this process) -- but only if that
+    profile was taken on the kernel being timed now: its recorded kernel time must agree within 10 %."""
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*", "*_pmc_summary.json")):
+        rnd = os.path.basename(os.path.dirname(path))
+        tag = os.path.basename(path).split("_")[0]
+        try:
+            key = (int(rnd[1:]), int(tag[1:]))
+        except ValueError:
+            continue
+        if best is None or key > best[0]:
+            best = (key, path)
+    if best is None:
+        return None, None
+    try:
+        s = json.load(open(best[1]))
+        rec = s.get("kernel_ms_per_launch")
+        if rec is None or abs(rec - kernel_ms) > 0.10 * kernel_ms:
+            return None, os.path.relpath(best[1], ROOT) + " (stale: recorded kernel time differs from the measured one)"
+        return s["hbm_bytes_per_launch"], os.path.relpath(best[1], ROOT)
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,12 +178,19 @@ def main():
                     help="only the headline workload (used under rocprofv3 so that the kernel statistics are the headline's)")
     args = ap.parse_args()
 
+    if os.environ.get("SLIP_HIP_LIBRARY"):
+        raise SystemExit("bench.py measures the in-tree HIP library only: unset SLIP_HIP_LIBRARY")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(subprocess.call(relaunch_distributed(args)))
+
     import numpy as np
     import torch
     import slip_lu_amd as sl
-    from slip_lu_amd import parallel
+    from slip_lu_amd import parallel, _lib
 
     rank, world, local = parallel.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -129,19 +234,16 @@ def main():
     assert K == idx["K"] and nnz == idx["lnz"] + idx["unz"] - idx["K"], "benchmark run differs from the reference window"
     assert info["b_read"] == idx["counters"]["B_read"] and info["b_write"] == idx["counters"]["B_write"]
 
-    # HBM traffic per launch from the PMC passes of this round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    # separate runs; profiles/r01/v8_pmc_summary.json): counters cannot be read from inside this process
-    traffic = None
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01", "v8_pmc_summary.json")))["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    ms_per_step = 1e3 * elapsed / args.steps
+    kms = kernel_ms / args.steps                       # HIP-event time of the column-loop kernel per launch
+    traffic, traffic_src = profile_traffic(kms)
 
-    # secondary, complete-run workloads (LP bases / ExampleMats of the reference): one run each
+    # secondary, complete-run workloads (LP bases / ExampleMats of the reference): one run each, with the
+    # compiled reference timed on this host's cores (1 core) in the same run
     secondary = []
     if rank == 0 and world == 1 and not args.no_secondary:
         from conftest import load_case
-        for name in ("10teams", "prob159", "NSR8K_w600", "rl5934"):
+        for name in SECONDARY:
             try:
                 e, fx = load_case(name)
                 g = sl.Factorization(e["n"], fx["Ap"], fx["Ai"], fx["Alen"], fx["Alimbs"], fx["q"], limb_cap=e["cap"])
@@ -150,8 +252,8 @@ def main():
                 nz = gi["lnz"] + gi["unz"] - gi["K"]
                 assert nz == e["lnz"] + e["unz"] - e["K"] and gi["b_read"] == e["counters"]["B_read"]
                 rec = dict(workload=name, columns=gi["K"], lu_nnz=nz, max_limbs=gi["max_limbs"],
-                           kernel_ms=gi["kernel_ms"], lu_nnz_per_s=nz / (gi["kernel_ms"] * 1e-3),
-                           reference_cpu_seconds_build_container=e["ref_seconds"])
+                           kernel_ms=gi["kernel_ms"], launches=gi["launches"], lu_nnz_per_s=nz / (gi["kernel_ms"] * 1e-3),
+                           algorithmic_read_GBs=gi["b_read"] / (gi["kernel_ms"] * 1e-3) / 1e9)
                 if gi["K"] == e["n"]:
                     # next row of the scope table: SLIP_LU_solve's substitutions on the resident factors, one
                     # right-hand side (the deterministic b of the solve goldens), second run timed
@@ -160,14 +262,19 @@ def main():
                     g.solve(bl, bx); g.solve(bl, bx)
                     rec["solve_kernel_ms"] = g.solve_ms()
                 g.close()
+                if not args.no_cpu_baseline:
+                    tf, ts = reference_seconds(name, e, fx)
+                    rec["reference_cpu_seconds"] = tf
+                    rec["reference_cpu_solve_seconds"] = ts
+                    if tf:
+                        rec["gpu_over_cpu"] = tf / (gi["kernel_ms"] * 1e-3)
                 secondary.append(rec)
             except Exception as ex:                  # never let a side measurement break the headline
                 secondary.append(dict(workload=name, error=str(ex)))
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    kms = kernel_ms / args.steps                       # HIP-event time of the column-loop kernel per launch
     value = world * nnz / (elapsed / args.steps)
     achieved = info["b_read"] / (kms * 1e-3) / 1e9     # GB/s, algorithmic reads
+    digit_macs = 4 * info["limb_macs"] / (kms * 1e-3)
     out = {
         "metric": "L+U nonzeros/sec on random n=100k 0.1%-dense CSC; achieved HBM GB/s vs peak",
         "value": value, "unit": "L+U nonzeros/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -176,12 +283,18 @@ def main():
         "config": {"workload": "C4: random CSC n=100000 density=0.001 |a|<2^16 seed=1, COLAMD order (fixture), "
                                "default pivoting, column window until a value exceeds 64 limbs",
                    "columns": K, "lu_nnz": nnz, "n_upd": info["n_upd"], "max_limbs": info["max_limbs"],
-                   "parallelism": "replicas" if world > 1 else "1 GPU"},
+                   "parallelism": "replicas" if world > 1 else "1 GPU",
+                   "library": os.path.relpath(_lib.library_path(), ROOT), "version": f.lib.slip_hip_version().decode()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "slip_factor_kernel", "kernel_ms_per_launch": kms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "slip_factor_kernel", "kernel_ms_per_launch": kms, "workers": info["workers"], "waves": info["waves"],
+                     "lds_bytes_per_worker": info["lds_bytes"],
                      "algorithmic_read_bytes": info["b_read"], "algorithmic_write_bytes": info["b_write"],
-                     "achieved_read_plus_write": (info["b_read"] + info["b_write"]) / (kms * 1e-3) / 1e9},
+                     "achieved_read_plus_write": (info["b_read"] + info["b_write"]) / (kms * 1e-3) / 1e9,
+                     "alu": {"limb_macs": info["limb_macs"], "digit_macs_per_s": digit_macs, "peak": DIGIT_MAC_PEAK,
+                             "frac": digit_macs / DIGIT_MAC_PEAK,
+                             "note": "algorithmic: 4 x (l(L_m) l(x_j) + l(x_i) l(rho_jn)) 32-bit multiply-adds per IPGE update "
+                                     "(SURVEY 8(d)); peak = v_mad_u64_u32 at a quarter of the VALU lane rate"}},
     }
     if secondary:
         out["secondary"] = secondary

@@ -29,9 +29,12 @@
  *
  * Memory visibility between workers (cdna_hip_programming.md, Guideline 16): everything another worker
  * may read during the launch (pinv, row_perm, pivot records, L structure and limbs, the inverse cache,
- * the frontier words) is written with write-through (sc1) stores, drained (vmcnt(0)) by every storing
- * wave before ONE lane raises the flag, and read ONLY with sc1 loads (slip_ld_*), so no acquire fence is
- * needed on the reading side.  A worker's x vector is private (plain accesses).  Nothing depends on
+ * the frontier words) is read ONLY with sc1 loads (slip_ld_*: they bypass the reading CU's L1), so no acquire
+ * fence is needed on the reading side.  On the writing side the small stage-1 data (the pivot's digits and
+ * record, the permutation swap, the column pointers) and the inverse cache use write-through (sc1) stores,
+ * drained (vmcnt(0)) by every storing wave before ONE lane raises the flag; the bulk of a column (L entries
+ * and limbs) is written with plain coalesced stores and published by ONE agent-scope release fence (L2
+ * write-back) before Lready[k].  A worker's x vector is private (plain accesses).  Nothing depends on
  * dispatch order or residency: a workgroup that is not resident holds no ticket.
  *
  * Values are sign-magnitude: a signed digit count (32-bit digits) plus the magnitude; all stores are
@@ -97,6 +100,8 @@ typedef struct SlipParams {
     int32_t *Lready;                                /* shared: column c's L entries and limbs are published (stage 2)  */
     int32_t *pat;                                   /* PRIVATE: pattern of the column (positions, ascending) when it exceeds the LDS cap */
     int32_t *rlist;                                 /* PRIVATE: rows of the pattern in discovery order                  */
+    int32_t *rpos;                                  /* PRIVATE: their positions at commit time (patterns beyond the LDS cap) */
+    int32_t *srow;                                  /* PRIVATE: rows in pattern order (patterns beyond the LDS cap)       */
     uint32_t *gscratch, *gbitmap;                   /* PRIVATE: used when LDS does not hold them */
     int32_t k0, t0;                                 /* ticket t0 + d is column k0 + d in this launch                    */
     int32_t bitmap_in_lds, scratch_in_lds;          /* where the bitmap / wave scratch live (generic kernel)            */
@@ -131,6 +136,8 @@ typedef struct SlipSolveArgs {
 #define SLIP_LDS_WORK      192      /* work lists: 2 x SLIP_WORK_CAP (m, i) pairs, or 1 x rows + 1 x 5-word row records */
 #define SLIP_WORK_CAP      512
 #define SLIP_WORK_WORDS    (6 * SLIP_WORK_CAP)
+#define SLIP_FAST_CAP       SLIP_TAB_CAP    /* patterns up to this many rows may commit their pivot early */
+#define SLIP_CAND_CAP       SLIP_WORK_CAP   /* ... if no more than this many candidates of either kind need arithmetic */
 #define SLIP_LDS_TAB       (SLIP_LDS_WORK + SLIP_WORK_WORDS)   /* column table: row, len, bits, slab offset per pattern entry */
 #define SLIP_TAB_CAP       1024
 #define SLIP_PAT_CAP       1024     /* a pattern of at most this many entries stays in LDS               */
@@ -145,7 +152,7 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
        SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14,
        SV_LALLOC = 16 /* limbs of the L slab handed out to this column's direct rows */, SV_LEXACT = 18,
        SV_NROWS = 24 /* rows discovered so far (length of rlist) */, SV_K = 25, SV_TAG = 26, SV_ABORT = 27,
-       SV_TMP2 = 28, SV_F2 = 29 /* ready frontier as this worker knows it */ };
+       SV_TMP2 = 28, SV_F2 = 29 /* ready frontier as this worker knows it */, SV_TMP3 = 30, SV_ACNT = 31 /* class-A rows of the early commit (zeroed at column start) */ };
 
 SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
 SLIP_DEV int slip_abs(int32_t v) { return v < 0 ? -v : v; }
@@ -514,10 +521,12 @@ SLIP_DEV int slip_ensure_inv_any(const SlipParams &P, int p, int want, dig_t *b0
 }
 
 /* History update of row r (slip_REF_triangular_solve.c:139-149, 248-257), one wavefront:
- *     x[r] <- x[r] * rho[pm] / rho[pd]      (pd < 0: no division); the history tag is kept */
-template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, int pm, int pd, dig_t *b0)
+ *     x[r] <- x[r] * rho[pm] / rho[pd]      (pd < 0: no division); the row's history tag becomes newh (SLIP_KEEP_H: stays) */
+#define SLIP_KEEP_H (-1000000000)
+template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, int pm, int pd, dig_t *b0, int newh)
 {
-    const SlipRow xr = P.xrow[r];
+    SlipRow xr = P.xrow[r];
+    if (newh != SLIP_KEEP_H) xr.h = newh;
     const int lx = slip_abs(xr.len);
     const SlipPiv m = slip_ld_piv(&P.piv[pm]);
     const int lm = slip_abs(m.len);
@@ -538,9 +547,10 @@ template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, 
     return slip_store_x_reg<D>(P, r, Y, sign, xr.h, xr.tag);
 }
 
-SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2)
+SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2, int newh)
 {
-    const SlipRow xr = P.xrow[r];
+    SlipRow xr = P.xrow[r];
+    if (newh != SLIP_KEEP_H) xr.h = newh;             /* the history tag the updated row carries */
     const int lx = slip_abs(xr.len);
     const dig_t *X = P.xd + (int64_t) r * P.xcap;
     const SlipPiv m = slip_ld_piv(&P.piv[pm]);
@@ -552,10 +562,10 @@ SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t
         int Wn = (bq + 31) >> 5;
         if (pd >= 0) { const SlipPiv d0 = slip_ld_piv(&P.piv[pd]); Wn = ((bq - d0.bits + 1 + 31) >> 5) + ((d0.ctz + 31) >> 5); }
         if (Wn > P.wcap) return 1;
-        if (Wn <= 64)  return slip_history_wave_reg<1>(P, r, pm, pd, b0);
-        if (Wn <= 128) return slip_history_wave_reg<2>(P, r, pm, pd, b0);
-        if (Wn <= 192) return slip_history_wave_reg<3>(P, r, pm, pd, b0);
-        if (Wn <= 256) return slip_history_wave_reg<4>(P, r, pm, pd, b0);
+        if (Wn <= 64)  return slip_history_wave_reg<1>(P, r, pm, pd, b0, newh);
+        if (Wn <= 128) return slip_history_wave_reg<2>(P, r, pm, pd, b0, newh);
+        if (Wn <= 192) return slip_history_wave_reg<3>(P, r, pm, pd, b0, newh);
+        if (Wn <= 256) return slip_history_wave_reg<4>(P, r, pm, pd, b0, newh);
     }
     /* wide operands (see slip_ensure_inv) */
     slip_agent_acquire();
@@ -801,15 +811,43 @@ SLIP_DEV int slip_cmp_mag(const dig_t *a, int sa, const dig_t *b, int sb, int l)
  * rec3: word 3 of the row's record = (pattern index << 3) | (negative << 2) | digits of the one-limb value;
  * ctab != null (this workgroup's LDS): also enter the row into the column table and its leading 64 bits into the key
  * list, so that the pivot search does not read back through memory what this CU has just produced */
+/* what the early commit wants to know about a candidate row it has just multiplied (LDS arrays indexed by the row's
+ * place in the worker's row table): the search key, the low limb and the trailing zeros for the pivot record */
+struct SlipCandOut { uint32_t *k0, *k1, *lo0, *lo1, *ctz; int kind; };
+
 template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const SlipPiv &M, const WR<D> &Y, int r, uint32_t rec3, int64_t off,
-                                                   uint32_t slot_off, uint32_t *ctab, uint32_t *ckeys, int tag)
+                                                   uint32_t slot_off, uint32_t *ctab, uint32_t *ckeys, int tag, const SlipCandOut *co = (const SlipCandOut *) 0)
 {
     const int len = wr_len<D>(Y);
-    wr_store_s<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
+    /* bulk L data: plain (coalesced) stores; the worker's release fence before Lready[k] publishes them (a 4-byte
+     * write-through store is one fabric write per lane: 6x the time of these rows).  A candidate of the early commit may
+     * become the pivot, which later columns read as soon as the frontier moves: written through. */
+    if (co) wr_store_s<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
+    else    wr_store_g<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
     const uint32_t d1 = len ? wr_digit<D>(Y, len - 1) : 0u;
     const int neg = (int)((rec3 >> 2) & 1u) ^ (M.len < 0);
     const int32_t slen = neg ? -len : len;
     const int bits = len ? 32 * len - slip_clz32(d1) : 0;
+    if (co) {
+        const uint32_t d2 = len >= 2 ? wr_digit<D>(Y, len - 2) : 0u, d3 = len >= 3 ? wr_digit<D>(Y, len - 3) : 0u;
+        const uint32_t l0 = wr_digit<D>(Y, 0), l1 = wr_digit<D>(Y, 1);
+        int z = 0;
+#pragma unroll
+        for (int q = D - 1; q >= 0; q--) {
+            const uint64_t nz = slip_ballot(Y.d[q] != 0);
+            if (nz) { const int tl_ = slip_ctz64(nz); z = 32 * (64 * q + tl_) + slip_ctz32(slip_readlane(Y.d[q], tl_)); }
+        }
+        if (slip_lane() == 0) {
+            uint64_t top = ((uint64_t) d1 << 32) | d2;
+            const int sh = len ? slip_clz32(d1) : 0;
+            if (sh) top = (top << sh) | (uint64_t)(d3 >> (32 - sh));
+            const int ti = (int)(rec3 >> 3);
+            uint64_t key = ((uint64_t) bits << 40) | (top >> 24);
+            if (co->kind == 1) key = ~key;
+            co->k0[ti] = (uint32_t) key; co->k1[ti] = (uint32_t)(key >> 32);
+            co->lo0[ti] = l0; co->lo1[ti] = l1; co->ctz[ti] = (uint32_t) z;
+        }
+    }
     if (ctab) {
         const uint32_t d2 = len >= 2 ? wr_digit<D>(Y, len - 2) : 0u, d3 = len >= 3 ? wr_digit<D>(Y, len - 3) : 0u;
         if (slip_lane() == 0) {
@@ -832,7 +870,8 @@ template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const Sl
 }
 
 template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipPiv &M, const dig_t *Md, int md_shared, const uint32_t *recs,
-                                                int first, int stride, int nrows, int64_t slab_base, uint32_t *ctab, uint32_t *ckeys, int tag)
+                                                int first, int stride, int nrows, int64_t slab_base, uint32_t *ctab, uint32_t *ckeys, int tag,
+                                                const SlipCandOut *co)
 {
     const int lane = slip_lane();
     const WR<D> Mr = md_shared ? wr_load_s<D>(Md, slip_abs(M.len)) : wr_load<D>(Md, slip_abs(M.len));
@@ -846,8 +885,8 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
         if ((w0 & 3u) != 1u || (w1 & 3u) != 1u) break;
         WR<D> Y0, Y1;
         wr_mul_digit2<D>(recs[5 * t + 1], recs[5 * u + 1], Mr, Y0, Y1);
-        slip_mul_row_finish<D>(P, M, Y0, (int) recs[5 * t], w0, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag);
-        slip_mul_row_finish<D>(P, M, Y1, (int) recs[5 * u], w1, slab_base + (int64_t) recs[5 * u + 4], recs[5 * u + 4], ctab, ckeys, tag);
+        slip_mul_row_finish<D>(P, M, Y0, (int) recs[5 * t], w0, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag, co);
+        slip_mul_row_finish<D>(P, M, Y1, (int) recs[5 * u], w1, slab_base + (int64_t) recs[5 * u + 4], recs[5 * u + 4], ctab, ckeys, tag, co);
     }
     for (; t < nrows; t += stride) {
         const uint32_t w = recs[5 * t + 3];
@@ -859,7 +898,7 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
             if (lane == 1) A.d[0] = recs[5 * t + 2];
             Y = wr_mul<D>(A, (int)(w & 3u), Mr);
         }
-        slip_mul_row_finish<D>(P, M, Y, (int) recs[5 * t], w, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag);
+        slip_mul_row_finish<D>(P, M, Y, (int) recs[5 * t], w, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag, co);
     }
     return 0;
 }
@@ -867,13 +906,13 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
 /* rows [first, first+stride, ...) of a column's one-limb-times-pivot list (5-word records), pivot M = rho[k-1];
  * Md: staged copy of the pivot's digits in LDS (md_shared 0), or the L slab itself (md_shared 1) */
 SLIP_DEV int slip_mul_rows_any(const SlipParams &P, const SlipPiv &M, const dig_t *Md, int md_shared, const uint32_t *recs, int first, int stride, int nrows,
-                               int64_t slab_base, uint32_t *ctab, uint32_t *ckeys, int tag)
+                               int64_t slab_base, uint32_t *ctab, uint32_t *ckeys, int tag, const SlipCandOut *co = (const SlipCandOut *) 0)
 {
     const int Dm = (slip_abs(M.len) + 2 + 63) >> 6;
-    if (Dm <= 1) return slip_mul_rows_reg<1>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag);
-    if (Dm == 2) return slip_mul_rows_reg<2>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag);
-    if (Dm == 3) return slip_mul_rows_reg<3>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag);
-    return slip_mul_rows_reg<4>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag);
+    if (Dm <= 1) return slip_mul_rows_reg<1>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag, co);
+    if (Dm == 2) return slip_mul_rows_reg<2>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag, co);
+    if (Dm == 3) return slip_mul_rows_reg<3>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag, co);
+    return slip_mul_rows_reg<4>(P, M, Md, md_shared, recs, first, stride, nrows, slab_base, ctab, ckeys, tag, co);
 }
 
 /* ---- REF triangular solves (SLIP_LU_solve.c:41-86): the two extra wave-level operations ---- */
@@ -921,8 +960,8 @@ SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, 
     if (kind == 1) return slip_ipge_wave(P, (int) items[2 * t + 1], j, jn, m0 + (int64_t) items[2 * t], b0, b1, b2);
     if (kind == 5) return slip_submul_wave(P, (int) items[2 * t + 1], j, m0 + (int64_t) items[2 * t], b0, b1, b2);
     const int r = (int) items[t];
-    if (kind == 4) return slip_history_wave(P, r, k - 1, -1, b0, b1, b2);      /* x * rho[k-1] */
-    return slip_history_wave(P, r, k - 1, P.xrow[r].h, b0, b1, b2);
+    if (kind == 4) return slip_history_wave(P, r, k - 1, -1, b0, b1, b2, SLIP_KEEP_H);      /* x * rho[k-1] */
+    { const int h = P.xrow[r].h; return slip_history_wave(P, r, k - 1, h, b0, b1, b2, k - 1); }   /* now at level k-1 */
 }
 
 /* ---- out-of-line entry points (one copy each; the parameters are the workgroup's LDS copy) ---- */
@@ -933,7 +972,7 @@ SLIP_DEVN int slip_run_item_out(const SlipParams *Pg, int kind, int j, int jn, i
 }
 SLIP_DEVN int slip_history_wave_out(const SlipParams *Pg, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2)
 {
-    return slip_history_wave(*Pg, r, pm, pd, b0, b1, b2);
+    return slip_history_wave(*Pg, r, pm, pd, b0, b1, b2, SLIP_KEEP_H);
 }
 SLIP_DEVN int slip_divexact_out(const SlipParams *Pg, int r, int p, dig_t *b0, dig_t *b1, dig_t *b2)
 {

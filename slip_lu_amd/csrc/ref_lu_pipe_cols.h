@@ -24,7 +24,10 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k)
             if (F >= need) { res = F; break; }
             const int64_t stop = slip_ld_i64(&st->stop);
             if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
-            if (need - F <= 2) slip_sleep_short(); else slip_sleep();
+            /* the further from its turn, the longer between polls: the frontier word is one line for the whole chip */
+            const int dist = k - F;
+            if (dist <= 1) slip_sleep_short();
+            else { const int reps = dist < 32 ? dist : 32; for (int q = 0; q < reps; q++) slip_sleep(); }
             if (++spins > SLIP_SPIN_LIMIT) { slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
         }
         sv[SV_TMP2] = res;
@@ -93,12 +96,13 @@ SLIP_DEV void slip_rlist_push(const SlipParams &P, volatile int32_t *sv, int has
 template <bool FAST, bool GATED>
 SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const int tag, uint32_t *lds, uint32_t *bm, dig_t *b0, dig_t *b1, dig_t *b2,
                         unsigned long long &c_read, unsigned long long &c_upd, unsigned long long &c_src, unsigned long long &c_str,
-                        unsigned long long &c_mac)
+                        unsigned long long &c_mac, unsigned long long *t_wait, unsigned long long *t_last)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave();
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     uint32_t *work = lds + SLIP_LDS_WORK;
     int cur = -1, step = 0;
+    (void) t_wait; (void) t_last;
     int pj = -1, pjn = -1;                       /* the source whose queued (wave) updates are pending */
     int dj = -1, dys = 1, dh = -1;               /* finalised one-limb source value not yet written back */
     slip_u128 dy = 0;
@@ -119,7 +123,13 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
         if (jn < 0) {
             if (!GATED || Fl >= k) break;        /* the sweep is complete */
             /* wait for the frontier to move; the rows of the pattern that became pivotal are row_perm[c], c in [Fl, Fn) */
+#ifdef SLIP_PROFILING
+            const unsigned long long tw0_ = slip_clock();
+#endif
             int Fn = slip_wait_frontier(st, lds, Fl + 1, k);
+#ifdef SLIP_PROFILING
+            *t_last = slip_clock(); t_wait[0] += *t_last - tw0_;
+#endif
             if (Fn < 0) return 1;
             if (Fn > k) Fn = k;
             for (int c = Fl + tid; c < Fn; c += T) {
@@ -132,7 +142,13 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
         cur = jn;
         if (GATED && jn >= sv[SV_F2]) {
             /* the source is committed but its L column may still be on its way (stage 2 of column jn) */
+#ifdef SLIP_PROFILING
+            const unsigned long long tw0_ = slip_clock();
+#endif
             const int f2 = slip_wait_ready(P, st, lds, jn + 1);
+#ifdef SLIP_PROFILING
+            t_wait[1] += slip_clock() - tw0_;
+#endif
             if (f2 < 0) return 1;
             if (tid == 0) sv[SV_F2] = f2;
             slip_block_sync();
@@ -259,8 +275,8 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
     return 0;
 }
 
-/* bitmap -> pattern: positions in ascending order (what slip_sort_xi.c produces) in LDS (or P.pat when long),
- * the rows behind them next to it; *nU_out = how many of them are below k.  Called by all threads; ends before a barrier. */
+/* bitmap -> pattern: positions in ascending order (what slip_sort_xi.c produces) in LDS (or P.pat when long);
+ * *nU_out = how many of them are below k.  Called by all threads; ends before a barrier. */
 SLIP_DEV void slip_pattern(const SlipParams &P, uint32_t *lds, const uint32_t *bm, int k, int *npat_out, int *nU_out)
 {
     const int tid = slip_tid(), T = slip_nthreads();
@@ -294,12 +310,6 @@ SLIP_DEV void slip_pattern(const SlipParams &P, uint32_t *lds, const uint32_t *b
             }
         }
     }
-    /* the rows behind the positions, gathered once for the phases that follow (one parallel round of loads) */
-    if (totA <= SLIP_PAT_CAP) {
-        int32_t *patl = (int32_t *)(lds + SLIP_LDS_PAT), *rowl = (int32_t *)(lds + SLIP_LDS_ROWS);
-        slip_block_sync();
-        for (int t = tid; t < (int) totA; t += T) rowl[t] = slip_ld_i32(&P.row_perm[patl[t]]);
-    }
     *npat_out = (int) totA; *nU_out = (int) totU_;
 }
 
@@ -314,7 +324,7 @@ SLIP_DEV int slip_publish_digits(dig_t *dst, const dig_t *src, int src_shared, i
         const int c = base + lane;
         uint32_t v = 0;
         if (c < len) v = src_shared ? slip_ld_u32(src + c) : src[c];
-        if (c < lw && (!src_shared || dst != src)) slip_st_u32(dst + c, v);
+        if (c < lw) slip_st_u32(dst + c, v);              /* also when it is in place already: plain-stored there, written through here */
         if (ctz < 0) {
             const uint64_t nz = slip_ballot(v != 0);
             if (nz) { const int t = slip_ctz64(nz); ctz = 32 * (base + t) + slip_ctz32(slip_shfl_u32(v, t)); }
@@ -350,7 +360,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     /* ---- phase 0: clear the pattern bitmap, take a snapshot of the commit frontier ---- */
     for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
     if (tid == 0) {
-        sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv[SV_NROWS] = 0;
+        sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv[SV_NROWS] = 0; sv[SV_ACNT] = 0;
         sv64[SV_LALLOC / 2] = 0; sv64[SV_LEXACT / 2] = 0;
         /* the ready frontier first: it never passes the commit frontier, also not between the two loads */
         sv[SV_F2] = slip_ld_i32(&st->F2);
@@ -390,39 +400,398 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     SLIP_STAMP(0);
 
     /* ---- phase 2: ascending sweep over the pivotal part of the pattern, ahead of the frontier ---- */
-    if (slip_sweep<FAST, true>(P, st, k, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac)) return SLIPDEV_ABORTED;
+    unsigned long long t_wait_[2] = {0, 0}, t_last_ = 0;
+    if (slip_sweep<FAST, true>(P, st, k, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac, t_wait_, &t_last_)) return SLIPDEV_ABORTED;
     slip_block_sync();
     if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
     SLIP_STAMP(1);
+#ifdef SLIP_PROFILING
+    /* slot 1: the sweep's own work; 16/17: waiting for the commit / ready frontier; 19: columns counted */
+    if (tid == 0) { prof_[1] -= t_wait_[0] + t_wait_[1]; prof_[16] += t_wait_[0]; prof_[17] += t_wait_[1]; prof_[19] += 1;
+                    if (t_last_) prof_[20] += t_prev_ - t_last_; }      /* 20: sweep work after the last frontier wait (on the commit chain) */
+#endif
     /* from here on F == k: columns 0..k-1 are committed, pinv / row_perm are those of the reference at column k */
 
-    /* ---- phase 3: the rows that are still non-pivotal take their (now final) positions; reading the
-     *      bitmap in order = the sorted pattern (slip_sort_xi.c) ---- */
-    {
-        const int nrows = sv[SV_NROWS];
-        for (int t = tid; t < nrows; t += T) {
-            const int r = P.rlist[t];
-            const int pos = slip_ld_i32(&P.pinv[r]);
+    /* ---- phase 3: snapshot of the rows' positions and states.  F == k, so pinv is the reference's at column k; once
+     *      this column has published its pivot (which may happen BEFORE its bulk is written, see the early commit
+     *      below) later columns swap pinv / row_perm again, so everything after this point works on the snapshot.
+     *      One round of loads: per row pinv[r] and the row state; rho[k-1]'s record; the column cursors. ---- */
+    const int nrows = sv[SV_NROWS];
+    const bool small = nrows <= SLIP_TAB_CAP;
+    uint32_t *f_row = lds + SLIP_LDS_TAB, *f_pos = f_row + SLIP_TAB_CAP, *f_inf = f_pos + SLIP_TAB_CAP, *f_aux = f_inf + SLIP_TAB_CAP;
+    uint32_t *f_k0 = lds + SLIP_LDS_KEYS, *f_k1 = f_k0 + SLIP_PAT_CAP;                    /* search keys of exact candidates */
+    uint32_t *c_lo0 = lds + SLIP_LDS_PAT, *c_lo1 = lds + SLIP_LDS_ROWS, *c_ctz = lds + SLIP_LDS_DIROFF;   /* free until phase 3c */
+    const int scheme = P.pivot_scheme;
+    const int kind = (scheme == 2) ? 2 : ((scheme == 4 || scheme == 5) ? 1 : 0);   /* 0 smallest, 1 largest, 2 first nonzero */
+    const bool try_early = k >= 1 && nrows <= SLIP_FAST_CAP;
+    SlipPiv M = slip_piv_none();
+    if (k >= 1) M = slip_ld_piv(&P.piv[k - 1]);
+    const int lm = slip_abs(M.len), brho = M.bits;
+    const int slot = (lm + 3) >> 1;
+    if (tid == 0) {
+        sv64[SV_LNZ / 2] = slip_ld_i64(&P.Lp[k]); sv64[SV_LNL / 2] = slip_ld_i64(&P.Lo[k]);
+        sv64[SV_UNZ / 2] = slip_ld_i64(&P.Up[k]); sv64[SV_UNL / 2] = slip_ld_i64(&P.Uo[k]);
+        sv[SV_TMP3] = slip_ld_i32(&P.pinv[col]);        /* position of the "diagonal" row: fixed until this column's swap */
+        sv[SV_TMP] = slip_ld_i32(&P.row_perm[k]);       /* the row the pivot will change places with                    */
+        sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_LISTN] = 0;
+    }
+    /* class of a row for the early commit: 0 not a candidate (pivotal or zero), 1 exact (value at level k-1 in its x
+     * row), 2 pending A (one limb times the long pivot -> straight into the L slab), 3 pending B (wave item) */
+    uint64_t ulimbs = 0, lbound = 0; int nUc = 0, bad = 0, maxub = 0; uint32_t best_b = kind == 1 ? 0u : 0xFFFFFFFFu;
+    volatile int32_t *acnt = &sv[SV_ACNT];               /* zero since the column started: no barrier needed before the first slot is drawn */
+    for (int t0 = 0; t0 < nrows; t0 += T) {
+        const int t = t0 + tid;
+        int cls = 0, ub = 0, isA = 0, r = 0, pos = 0;
+        if (t < nrows) {
+            r = P.rlist[t];
+            pos = slip_ld_i32(&P.pinv[r]);
             slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
+            if (small) { f_row[t] = (uint32_t) r; f_pos[t] = (uint32_t) pos; } else P.rpos[t] = pos;
         }
-        if (tid == 0) {
-            sv64[SV_LNZ / 2] = slip_ld_i64(&P.Lp[k]); sv64[SV_LNL / 2] = slip_ld_i64(&P.Lo[k]);
-            sv64[SV_UNZ / 2] = slip_ld_i64(&P.Up[k]); sv64[SV_UNL / 2] = slip_ld_i64(&P.Uo[k]);
+        if (try_early && t < nrows) {
+            const SlipRow xr = P.xrow[r];
+            if (pos < k) { ulimbs += (uint64_t) slip_limbs(xr.len); nUc++; if (xr.bits > maxub) maxub = xr.bits; }
+            else if (xr.len == 0) cls = 0;
+            else if (xr.h >= k - 1) {
+                cls = 1; ub = xr.bits; lbound += (uint64_t) slip_limbs(xr.len);
+                f_k1[t] = 0xFFFFFFFFu; f_k0[t] = 0xFFFFFFFFu;        /* key not known yet: formed from the digits if it becomes a candidate */
+            } else {
+                slip_u128 y = 0; int ys = 1;
+                uint64_t xv = 0;
+                if (slip_abs(xr.len) <= 2) xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                if (slip_abs(xr.len) <= 2 && slip_history_small(P, xr, xv, M, xr.h, &y, &ys)) {
+                    slip_store_small(P, r, y, ys, k - 1, tag);        /* now at level k-1 */
+                    cls = 1; ub = slip_bits128(y); lbound += (uint64_t)((((ub + 31) >> 5) + 1) >> 1);
+                    /* the lane has the value: search key, low limb and trailing zeros from registers */
+                    const uint64_t top = ub ? (uint64_t)((y << (128 - ub)) >> 64) : 0ull;
+                    uint64_t key = ((uint64_t) ub << 40) | (top >> 24);
+                    if (kind == 1) key = ~key;
+                    f_k0[t] = (uint32_t) key; f_k1[t] = (uint32_t)(key >> 32);
+                    c_lo0[t] = (uint32_t) y; c_lo1[t] = (uint32_t)((uint64_t) y >> 32);
+                    const uint64_t ylo = (uint64_t) y, yhi = (uint64_t)(y >> 64);
+                    c_ctz[t] = (uint32_t)(ylo ? slip_ctz64(ylo) : 64 + slip_ctz64(yhi));
+                } else if (xr.h < 0 && slip_abs(xr.len) <= 2 && lm + 2 <= P.xcap && lm + 2 <= 256) {
+                    cls = 2; isA = 1; ub = xr.bits + brho;
+                } else {
+                    cls = 3;
+                    int bh = 0, zh = 0;
+                    if (xr.h >= 0) { const SlipPiv H = slip_ld_piv(&P.piv[xr.h]); bh = H.bits; zh = H.ctz; }
+                    ub = xr.bits + brho - bh + (xr.h >= 0 ? 1 : 0);
+                    if (ub < 1) ub = 1;
+                    /* the item's working width (slip_history_wave) must fit the scratch, the x stride and the inverse cache */
+                    const int Wn = ((ub + 31) >> 5) + ((zh + 31) >> 5) + 1;
+                    if (Wn > P.wcap || Wn > P.xcap || Wn > P.invcap || lm > P.wcap) bad = 1;
+                    lbound += (uint64_t)((ub + 63) >> 6);
+                }
+            }
+            if (ub > maxub) maxub = ub;
+        }
+        if (try_early) {
+            /* class A rows get their slots in the L slab now (slot index kept in the row's own x area, behind the value) */
+            const uint64_t am = slip_ballot(isA);
+            int abase = 0;
+            if (lane == 0 && am) abase = slip_atomic_add_i32((int32_t *) acnt, slip_popc64(am));
+            abase = (int) slip_shfl_u32((uint32_t) abase, 0);
+            if (isA) {
+                const int si = abase + slip_popc64(am & ((1ull << lane) - 1ull));
+                f_aux[t] = (uint32_t) si;
+                (P.xd + (int64_t) r * P.xcap)[2] = (uint32_t) si;
+            }
+            if (t < nrows) {
+                f_inf[t] = (uint32_t) cls | ((uint32_t) ub << 2);
+                if (cls) {
+                    const int lb = cls == 1 ? ub : (cls == 2 ? ub - 1 : (ub > 2 ? ub - 2 : 1));
+                    if (kind == 0) { if ((uint32_t) ub < best_b) best_b = (uint32_t) ub; }
+                    else if (kind == 1) { if ((uint32_t) lb > best_b) best_b = (uint32_t) lb; }
+                    else { if ((uint32_t) pos < best_b) best_b = (uint32_t) pos; }     /* first nonzero: by position */
+                }
+            }
+        }
+    }
+    /* rho[k-1]'s digits for the candidate multiplies: staged in LDS while the reduction below runs */
+    const bool BMs = SCR_LDS && lm <= wcap;
+    dig_t *Ms = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + nw * 3 * wcap : (dig_t *) 0;
+    if (try_early && BMs) { const dig_t *Mg = slip_piv_digits(P, M); for (int c = tid; c < lm; c += T) Ms[c] = slip_ld_u32(Mg + c); }
+    slip_block_sync();
+    const int pc_col = sv[SV_TMP3];
+#ifdef SLIP_PROFILING
+    const unsigned long long tr_t2_ = slip_clock();
+    const unsigned long long tr_sweep_ = t_last_ ? tr_t2_ - t_last_ : 0;      /* sweep tail + position snapshot */
+#endif
+    SLIP_STAMP(2);
+
+    /* where the digits of a row are: its x row (private), or (rows multiplied straight into L: h == -2) the slab (shared) */
+    auto row_direct = [&](int r) -> int { return P.xrow[r].h == -2; };
+    auto row_digits = [&](int r) -> const dig_t * {
+        const dig_t *X = P.xd + (int64_t) r * P.xcap;
+        return P.xrow[r].h == -2 ? (const dig_t *)(P.Llimbs + *(const int64_t *) X) : X;
+    };
+    /* the tolerance test of the diagonal preference between the best candidate `pr` and the diagonal row `col`
+     * (slip_get_pivot.c:89-118, 126-146): 1 = take the diagonal; *err: scratch too small */
+    auto diag_rule = [&](int pr, int *err) -> int {
+        if (scheme == 1 || P.tol_mode == 0) return 1;
+        const int lp_ = slip_abs(P.xrow[pr].len), lc_ = slip_abs(P.xrow[col].len);
+        /* tol_m has exactly 53 bits, so tol_m*|den| has 52 or 53 bits more than |den|: most columns
+         * are decided by the bit lengths alone */
+        const int te0 = P.tol_e;
+        const int bnum_ = (scheme == 3 ? P.xrow[pr].bits : P.xrow[col].bits) + (te0 < 0 ? -te0 : 0);
+        const int bden_ = (scheme == 3 ? P.xrow[col].bits : P.xrow[pr].bits) + (te0 > 0 ? te0 : 0);
+        if (bnum_ < 52 + bden_) return 0;
+        if (bnum_ > 53 + bden_) return 1;
+        /* exact comparison.  Every wave runs it redundantly in its own scratch.  A row that lives in the L
+         * slab is shared data: its digits are staged (sc1 loads) into scratch the comparison does not need
+         * at that point -- the denominator into b1 (free until the last step, when the denominator has
+         * been consumed), the numerator behind the product in b2. */
+        const int rn = scheme == 3 ? pr : col, rd = scheme == 3 ? col : pr;   /* |small|/|diag| or |diag|/|large| >= tol */
+        const int ln = scheme == 3 ? lp_ : lc_, ldn = scheme == 3 ? lc_ : lp_;
+        const dig_t *num = P.xd + (int64_t) rn * P.xcap, *den = P.xd + (int64_t) rd * P.xcap;
+        if (ldn + 2 > wcap) { *err = 1; return 0; }
+        if (row_direct(rd)) { slip_stage_shared(b1, row_digits(rd), ldn); den = b1; }
+        if (row_direct(rn)) {
+            if (ldn + 4 + ln > wcap) { *err = 1; return 0; }
+            slip_stage_shared(b2 + ldn + 4, row_digits(rn), ln); num = b2 + ldn + 4;
+        }
+        const int tk = slip_tol_compare_out(P.tol_m, P.tol_e, num, ln, den, ldn, b0, b1, b2, wcap);
+        if (tk < 0) { *err = 1; return 0; }
+        return tk;
+    };
+
+    /* ---- early commit: choose and publish the pivot BEFORE the column's bulk arithmetic.
+     * The final values are x * rho[k-1] / rho[h]; their bit lengths are known to within two bits from the operands'
+     * bit lengths, so only the rows whose bounds reach the best bound can be the pivot: those are brought to level
+     * k-1 now (one-limb rows were, in the lane, above), the exact search runs among them, the pivot is published
+     * (stage 1) and the frontier moves; every other row is multiplied / divided afterwards, off the commit chain.
+     * The column must be certain to complete: capacities, widths and the column-window cap are checked on the bounds
+     * first, otherwise the column takes the complete path below (everything computed, then the search, then the commit). */
+    int early = 0, e_pivrow = -1, e_pivpos = -1;
+    if (try_early) {
+        /* one fused reduction: sums (U limbs, L limb bound, pivotal rows), maxima (trouble flag, longest bound), best bound */
+        uint64_t red_u = ulimbs, red_l = lbound; uint32_t red_n = (uint32_t) nUc, red_bad = (uint32_t) bad, red_mx = (uint32_t) maxub;
+        uint32_t red_b = kind == 1 ? 0xFFFFFFFFu - best_b : best_b;           /* smaller is better in every kind */
+        for (int d = 32; d >= 1; d >>= 1) {
+            red_u += slip_shfl_u64(red_u, lane ^ d); red_l += slip_shfl_u64(red_l, lane ^ d);
+            red_n += slip_shfl_u32(red_n, lane ^ d);
+            { const uint32_t o = slip_shfl_u32(red_bad, lane ^ d); if (o > red_bad) red_bad = o; }
+            { const uint32_t o = slip_shfl_u32(red_mx, lane ^ d); if (o > red_mx) red_mx = o; }
+            { const uint32_t o = slip_shfl_u32(red_b, lane ^ d); if (o < red_b) red_b = o; }
+        }
+        if (lane == 0) {
+            scan_tmp[4 * wave] = red_u; scan_tmp[4 * wave + 1] = red_l;
+            scan_tmp[4 * wave + 2] = (uint64_t) red_n | ((uint64_t) red_bad << 32);
+            scan_tmp[4 * wave + 3] = (uint64_t) red_mx | ((uint64_t) red_b << 32);
         }
         slip_block_sync();
+        uint64_t U_l = 0, L_b = 0; uint32_t nUc_all = 0, bad_all = 0, maxub_all = 0, bb = 0xFFFFFFFFu;
+        for (int w = 0; w < nw; w++) {
+            U_l += scan_tmp[4 * w]; L_b += scan_tmp[4 * w + 1];
+            const uint64_t a2 = scan_tmp[4 * w + 2], a3 = scan_tmp[4 * w + 3];
+            nUc_all += (uint32_t) a2; if ((uint32_t)(a2 >> 32) > bad_all) bad_all = (uint32_t)(a2 >> 32);
+            if ((uint32_t) a3 > maxub_all) maxub_all = (uint32_t) a3;
+            if ((uint32_t)(a3 >> 32) < bb) bb = (uint32_t)(a3 >> 32);
+        }
+        SLIP_STAMP(21);                                     /* early: classification + reduction */
+        if (bb == 0xFFFFFFFFu) return SLIPDEV_SINGULAR;      /* no nonzero non-pivotal row at all (slip_get_smallest_pivot.c:93-96) */
+        const int nA = *acnt;
+        const uint32_t bestb = kind == 1 ? 0xFFFFFFFFu - bb : bb;
+        const int nLc = nrows - (int) nUc_all;
+        const int64_t Lnz_ = sv64[SV_LNZ / 2], Lnl_ = sv64[SV_LNL / 2], Unz_ = sv64[SV_UNZ / 2], Unl_ = sv64[SV_UNL / 2];
+        /* a pivot living in its x row gets a slot of its own behind the class-A slots: bound it by the longest value */
+        const uint64_t preserve = (uint64_t)((maxub_all + 63) >> 6) + 1;
+        const uint64_t Lb_total = (uint64_t) nA * (uint64_t) slot + preserve + L_b;
+        const uint64_t Ub_total = U_l + preserve;
+        int ok = bad_all == 0;
+        if (Lnz_ + nLc > P.Lcap_nz || Lnl_ + (int64_t) Lb_total > P.Lcap_nl) ok = 0;
+        if (Unz_ + (int) nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t) Ub_total > P.Ucap_nl) ok = 0;
+        if (P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) ok = 0;  /* the window may end here: decide on exact values */
+        const int diag_cand = (scheme == 1 || scheme == 3 || scheme == 4) && pc_col >= k && P.xrow[col].tag == tag && P.xrow[col].len != 0;
+        uint32_t *wlB = work, *wlA = work + SLIP_WORK_CAP;
+        volatile int32_t *cntA = &sv[SV_CNT0 + 1], *cntB = &sv[SV_CNT0 + 2];
+        if (ok) {
+            /* pass 2: the candidates.  Pending ones are listed for the waves: class A -> 5-word records (one limb times
+             * rho[k-1] straight into its slot of the L slab), class B -> history items. */
+            for (int t0 = 0; t0 < nrows; t0 += T) {
+                const int t = t0 + tid;
+                int wantA = 0, wantB = 0, r = 0;
+                if (t < nrows) {
+                    const uint32_t inf = f_inf[t];
+                    const int cls = (int)(inf & 3u), ub = (int)(inf >> 2);
+                    r = (int) f_row[t];
+                    int cand = 0;
+                    if (cls) {
+                        const int lb = cls == 1 ? ub : (cls == 2 ? ub - 1 : (ub > 2 ? ub - 2 : 1));
+                        if (kind == 0) cand = (uint32_t) lb <= bestb;
+                        else if (kind == 1) cand = (uint32_t) ub >= bestb;
+                        else cand = f_pos[t] == bestb;
+                        if (diag_cand && r == col) cand = 1;
+                    }
+                    f_inf[t] = inf | (cand ? 0x80000000u : 0u);         /* bit lengths stay far below 2^29 */
+                    wantA = cand && cls == 2; wantB = cand && cls == 3;
+                }
+                const uint64_t mA = slip_ballot(wantA), mB = slip_ballot(wantB);
+                int bA = 0, bB = 0;
+                if (lane == 0) {
+                    if (mA) bA = slip_atomic_add_i32((int32_t *) cntA, slip_popc64(mA));
+                    if (mB) bB = slip_atomic_add_i32((int32_t *) cntB, slip_popc64(mB));
+                }
+                bA = (int) slip_shfl_u32((uint32_t) bA, 0); bB = (int) slip_shfl_u32((uint32_t) bB, 0);
+                const uint64_t below = (1ull << lane) - 1ull;
+                if (wantA) {
+                    const int at = bA + slip_popc64(mA & below);
+                    if (at < SLIP_CAND_CAP) {
+                        const SlipRow xr = P.xrow[r];
+                        const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                        wlA[5 * at] = (uint32_t) r; wlA[5 * at + 1] = (uint32_t) xv; wlA[5 * at + 2] = (uint32_t)(xv >> 32);
+                        wlA[5 * at + 3] = ((uint32_t) t << 3) | (xr.len < 0 ? 4u : 0u) | (uint32_t) slip_abs(xr.len);
+                        wlA[5 * at + 4] = f_aux[t] * (uint32_t) slot;
+                    }
+                } else if (wantB) { const int at = bB + slip_popc64(mB & below); if (at < SLIP_CAND_CAP) wlB[at] = (uint32_t) r; }
+            }
+            slip_block_sync();
+            if (*cntA > SLIP_CAND_CAP || *cntB > SLIP_CAND_CAP) ok = 0;          /* too many candidates for the lists: the complete path */
+        }
+        if (ok) {
+            const int ncA = *cntA, ncB = *cntB;
+            if (ncA > 0) {
+                const SlipCandOut co = { f_k0, f_k1, c_lo0, c_lo1, c_ctz, kind };
+                const int e = slip_mul_rows_any(P, M, BMs ? Ms : slip_piv_digits(P, M), BMs ? 0 : 1, wlA, wave, nw, ncA, Lnl_, (uint32_t *) 0, (uint32_t *) 0, tag, &co);
+                if (e && lane == 0) sv[SV_ERR] = 1;
+            }
+            slip_vm_drain();                                  /* the candidates' write-through stores have left before anyone publishes */
+            slip_block_sync();
+            if (ncB > 0) slip_drain(P, lds, 2, 0, 0, k, 0, ncB, wlB, b0, b1, b2);
+            if (sv[SV_ERR]) return SLIPDEV_INTERNAL;          /* the bounds said this could not happen */
+            SLIP_STAMP(22);                                   /* early: candidate lists and arithmetic */
+            /* pass 3: exact search among the candidates (all exact now), slip_get_pivot.c:58-155: (bit length, leading
+             * bits) keys; the candidates that tie on the best key are compared exactly, then by position */
+            auto key_of = [&](int t) -> uint64_t {
+                if (kind == 2) return (uint64_t) f_pos[t];
+                const uint32_t inf = f_inf[t];
+                const int cls = (int)(inf & 3u);
+                uint64_t key = (uint64_t) f_k0[t] | ((uint64_t) f_k1[t] << 32);
+                if (cls == 3 || (cls == 1 && key == ~0ull)) {          /* value produced by a wave item / final before: key from its digits */
+                    const int r = (int) f_row[t];
+                    const SlipRow xr = P.xrow[r];
+                    const uint64_t top = slip_top64(row_digits(r), slip_abs(xr.len), xr.h == -2);
+                    key = ((uint64_t) xr.bits << 40) | (top >> 24);
+                    if (kind == 1) key = ~key;
+                }
+                return key;
+            };
+            uint64_t k1 = ~0ull;
+            for (int t = tid; t < nrows; t += T) {
+                if (!(f_inf[t] >> 31)) continue;
+                const uint64_t v = key_of(t);
+                f_k0[t] = (uint32_t) v; f_k1[t] = (uint32_t)(v >> 32);
+                if (v < k1) k1 = v;
+            }
+            const uint64_t mk = slip_block_min_u64(k1, scan_tmp);
+            uint32_t *tl = work;                              /* tie list: table indices */
+            for (int t = tid; t < nrows; t += T) {
+                if (!(f_inf[t] >> 31)) continue;
+                if (((uint64_t) f_k0[t] | ((uint64_t) f_k1[t] << 32)) != mk) continue;
+                const int at = slip_atomic_add_i32((int32_t *) &sv[SV_LISTN], 1);
+                if (at < SLIP_WORK_WORDS) tl[at] = (uint32_t) t;
+            }
+            slip_block_sync();
+            const int nc = sv[SV_LISTN];
+            int bt = -1;
+            const int kbits = kind == 2 ? 0 : (int)((kind == 0 ? mk : ~mk) >> 40);
+            for (int c = 0; c < nc; c++) {                    /* every wave performs the same reduction (wave-uniform, reads only) */
+                const int t = (int) tl[c];
+                if (bt < 0) { bt = t; continue; }
+                const int rb = (int) f_row[bt], rt = (int) f_row[t];
+                int cmp = 0;
+                if (kbits > 40)      /* at most 40 bits: equal keys are equal values */
+                    cmp = slip_cmp_mag(row_digits(rb), row_direct(rb), row_digits(rt), row_direct(rt), slip_abs(P.xrow[rt].len));
+                if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && f_pos[t] < f_pos[bt])) bt = t;
+            }
+            if (bt < 0) return SLIPDEV_INTERNAL;
+            e_pivrow = (int) f_row[bt]; e_pivpos = (int) f_pos[bt];
+            /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); col's value is exact: it was a candidate */
+            if (diag_cand && e_pivrow != col) {
+                int derr = 0;
+                const int take = diag_rule(e_pivrow, &derr);
+                if (derr) return SLIPDEV_GROW_X;
+                if (take) { e_pivrow = col; e_pivpos = pc_col; }
+            }
+            SLIP_STAMP(13);
+            /* stage 1, early: the pivot's digits to the L slab (its class-A slot, or the reserved slot behind those),
+             * the pivot record, the permutation swap, the column pointers (limb offsets from the bounds), the frontier */
+            const SlipRow pxr = P.xrow[e_pivrow];
+            const int pdirect = pxr.h == -2;
+            const int64_t poff = pdirect ? *(const int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) : Lnl_ + (int64_t) nA * slot;
+            const uint64_t plimbs = (uint64_t) slip_limbs(pxr.len);
+            if (wave == 0) {
+                const int lp_ = slip_abs(pxr.len);
+                dig_t *dst = (dig_t *)(P.Llimbs + poff);
+                int z; uint64_t lo64;
+                const int cand_direct = pdirect && (int)(f_inf[bt] & 3u) == 2 && e_pivrow == (int) f_row[bt];
+                if (cand_direct) {
+                    /* multiplied a moment ago: written through by the multiplying wave, low limb and zeros stashed */
+                    z = (int) c_ctz[bt]; lo64 = (uint64_t) c_lo0[bt] | ((uint64_t) c_lo1[bt] << 32);
+                } else {
+                    const dig_t *src = pdirect ? (const dig_t *) dst : P.xd + (int64_t) e_pivrow * P.xcap;
+                    z = slip_publish_digits(dst, src, pdirect, lp_);
+                    lo64 = pdirect ? slip_ld_u64((const uint64_t *) dst) : *(const uint64_t *) src;
+                    slip_vm_drain();
+                }
+                if (lane == 0) {
+                    SlipPiv pr; pr.off = poff; pr.len = pxr.len; pr.bits = pxr.bits; pr.ctz = z; pr.invlen = 0;
+                    pr.lo = lo64; pr.inv64 = 0; pr.pad = 0;
+                    if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
+                    slip_st_piv(&P.piv[k], pr);
+                    const int intermed = e_pivpos, intermed2 = sv[SV_TMP];
+                    slip_st_i32(&P.row_perm[k], e_pivrow); slip_st_i32(&P.row_perm[intermed], intermed2);
+                    slip_st_i32(&P.pinv[e_pivrow], k); slip_st_i32(&P.pinv[intermed2], intermed);
+                    slip_st_i64(&P.Up[k + 1], Unz_ + (int) nUc_all + 1); slip_st_i64(&P.Lp[k + 1], Lnz_ + nLc);
+                    slip_st_i64(&P.Uo[k + 1], Unl_ + (int64_t)(U_l + plimbs)); slip_st_i64(&P.Lo[k + 1], Lnl_ + (int64_t) Lb_total);
+                    slip_vm_drain();
+                    slip_st_i32(&st->F, k + 1);
+#ifdef SLIP_PROFILING
+                    if (t_last_) prof_[18] += slip_clock() - t_last_;
+                    {
+                        int32_t *tr = P.dbg + 8 * (int64_t) k; const unsigned long long nowc = slip_clock();
+                        tr[0] = t_last_ ? (int32_t)(nowc - t_last_) : -1; tr[1] = 1; tr[2] = ncA + ncB; tr[3] = nrows;
+                        tr[4] = (int32_t) tr_sweep_; tr[5] = (int32_t)(nowc - tr_t2_); tr[7] = P.worker;
+                    }
+#endif
+                    /* from now on the pivot row lives in the slab like a class-A row */
+                    if (!pdirect) {
+                        SlipRow nr = pxr; nr.h = -2; P.xrow[e_pivrow] = nr;
+                        *(int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) = poff;
+                    }
+                    sv64[SV_LALLOC / 2] = (int64_t)((uint64_t) nA * (uint64_t) slot + (pdirect ? 0ull : plimbs));
+                }
+            }
+            early = 1;
+            slip_block_sync();
+            SLIP_STAMP(6);
+#ifdef SLIP_PROFILING
+            if (tid == 0) { prof_[23] += 1; prof_[15] += (unsigned long long)(ncA + ncB); }   /* early commits; their candidates that needed arithmetic */
+#endif
+        }
     }
-    const int pc_col = slip_ld_i32(&P.pinv[col]);       /* position of the "diagonal" row: fixed until this column's swap */
+    /* ---- phase 3c: reading the bitmap in order = the sorted pattern (slip_sort_xi.c); every row goes to the place of
+     *      its snapshot position (binary search over the sorted positions) ---- */
     int npat_, nU_;
     slip_pattern(P, lds, bm, k, &npat_, &nU_);
     const int npat = npat_, nU = nU_, nL = npat - nU;
     const int32_t *patl = (const int32_t *)(lds + SLIP_LDS_PAT);
     auto pat_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? patl[t] : P.pat[t]; };
-    const int32_t *rowl = (const int32_t *)(lds + SLIP_LDS_ROWS);
+    int32_t *rowl = (int32_t *)(lds + SLIP_LDS_ROWS);
     uint32_t *diroff = lds + SLIP_LDS_DIROFF;
-    auto row_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? rowl[t] : slip_ld_i32(&P.row_perm[P.pat[t]]); };
+    auto row_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? rowl[t] : P.srow[t]; };
     slip_block_sync();
-    if (npat != sv[SV_NROWS]) return SLIPDEV_INTERNAL;  /* every discovered row has exactly one position */
-    SLIP_STAMP(2);
+    if (npat != nrows) return early ? SLIPDEV_INTERNAL : SLIPDEV_INTERNAL;      /* every discovered row has exactly one position */
+    for (int t = tid; t < nrows; t += T) {
+        const int r = small ? (int) f_row[t] : P.rlist[t];
+        const int pos = small ? (int) f_pos[t] : P.rpos[t];
+        int lo = 0, hi = npat - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pat_at(mid) < pos) lo = mid + 1; else hi = mid; }
+        if (npat <= SLIP_PAT_CAP) rowl[lo] = r; else P.srow[lo] = r;
+    }
+    slip_block_sync();
+    SLIP_STAMP(14);
 
     /* ---- phase 4: history update of the non-pivotal rows to level k-1 (:248-257) ---- */
     /* one-limb rows finished by a lane enter the column table (and the key list of the pivot search) from that lane's
@@ -434,17 +803,13 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         volatile int32_t *wcnt = &sv[SV_CNT0], *wcnt2 = &sv[SV_CNT0 + 1];
         if (tid == 0) { *wcnt = 0; *wcnt2 = 0; }
         uint32_t *wl2 = work + SLIP_WORK_CAP;              /* 5-word records, SLIP_WORK_CAP of them */
-        /* rho[k-1] is the multiplier of every row: stage its digits once (LDS when it fits) */
-        const SlipPiv M = slip_ld_piv(&P.piv[k - 1]);
-        const int lm = slip_abs(M.len);
+        /* rho[k-1] is the multiplier of every row: its digits are staged once (LDS when it fits; the early pass did it) */
         const dig_t *Mg = slip_piv_digits(P, M);
-        dig_t *Ms = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + nw * 3 * wcap : (dig_t *) 0;
         const dig_t *Md = Mg; int md_shared = 1;
-        if (SCR_LDS && lm <= wcap) { for (int c = tid; c < lm; c += T) Ms[c] = slip_ld_u32(Mg + c); Md = Ms; md_shared = 0; }
+        if (BMs) { if (!try_early) for (int c = tid; c < lm; c += T) Ms[c] = slip_ld_u32(Mg + c); Md = Ms; md_shared = 0; }
         slip_block_sync();
         SLIP_STAMP(8);
         uint32_t *wl = work;
-        const unsigned long long slot = (unsigned long long)((lm + 3) >> 1);
         for (int t0 = 0; t0 < nL; t0 += SLIP_WORK_CAP) {
             const int te = t0 + SLIP_WORK_CAP < nL ? t0 + SLIP_WORK_CAP : nL;
             const unsigned long long chunk_base = (unsigned long long) sv64[SV_LALLOC / 2];
@@ -460,13 +825,13 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 xr = P.xrow[r];
                 if (npat <= SLIP_PAT_CAP) diroff[nU + t] = 0xFFFFFFFFu;
                 }
-                if (t < te && !(xr.len == 0 || xr.h >= k - 1)) {
+                if (t < te && !(xr.len == 0 || xr.h >= k - 1 || xr.h == -2)) {     /* zero, already at level k-1, or already in the slab */
                 int done = 0;
                 if (slip_abs(xr.len) <= 2) {
                     xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
                     slip_u128 y = 0; int ys = 1;
                     if (slip_history_small(P, xr, xv, M, xr.h, &y, &ys)) {
-                        slip_store_small(P, r, y, ys, xr.h, tag);
+                        slip_store_small(P, r, y, ys, k - 1, tag);
                         if (npat <= SLIP_PAT_CAP) {          /* the lane has the value: table entry and pivot key from registers */
                             const int yb = slip_bits128(y), yl = (yb + 31) >> 5, pidx = nU + t;
                             ctab[0 * SLIP_TAB_CAP + pidx] = (uint32_t) r; ctab[1 * SLIP_TAB_CAP + pidx] = (uint32_t)(ys < 0 ? -yl : yl);
@@ -495,7 +860,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                         int len = lm;
                         if (carry) { X[len++] = (uint32_t) carry; if (carry >> 32) X[len++] = (uint32_t)(carry >> 32); }
                         if (len & 1) X[len] = 0;
-                        SlipRow nr; nr.len = (slip_sgn(xr.len) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = xr.h; nr.tag = tag;
+                        SlipRow nr; nr.len = (slip_sgn(xr.len) * slip_sgn(M.len)) < 0 ? -len : len; nr.h = k - 1; nr.tag = tag;
                         nr.bits = 32 * len - slip_clz32(X[len - 1]);
                         P.xrow[r] = nr;
                         done = 1;
@@ -515,7 +880,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                     const int at = base1 + slip_popc64(m1 & below);
                     wl2[5 * at] = (uint32_t) r; wl2[5 * at + 1] = (uint32_t) xv; wl2[5 * at + 2] = (uint32_t)(xv >> 32);
                     wl2[5 * at + 3] = ((uint32_t)(nU + t) << 3) | (xr.len < 0 ? 4u : 0u) | (uint32_t) slip_abs(xr.len);
-                    wl2[5 * at + 4] = (uint32_t)(chunk_base + (unsigned long long) at * slot);
+                    /* an early commit has handed out the slots already (index kept behind the row's value) */
+                    wl2[5 * at + 4] = early ? (P.xd + (int64_t) r * P.xcap)[2] * (uint32_t) slot
+                                            : (uint32_t)(chunk_base + (unsigned long long) at * slot);
                     if (npat <= SLIP_PAT_CAP) diroff[nU + t] = wl2[5 * at + 4];
                 } else if (cls == 2) {
                     wl[base2 + slip_popc64(m2 & below)] = (uint32_t) r;
@@ -524,8 +891,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             slip_block_sync();
             SLIP_STAMP(9);
             /* the slots handed out above must exist before anything is written into them */
-            const unsigned long long lalloc_now = chunk_base + (unsigned long long) *wcnt2 * slot;
-            if (sv64[SV_LNL / 2] + (int64_t) lalloc_now > P.Lcap_nl) return SLIPDEV_GROW_L;
+            const unsigned long long lalloc_now = early ? chunk_base : chunk_base + (unsigned long long) *wcnt2 * slot;
+            if (!early && sv64[SV_LNL / 2] + (int64_t) lalloc_now > P.Lcap_nl) return SLIPDEV_GROW_L;
             const int nq = *wcnt;
             const int n2 = *wcnt2;
             const int64_t sb = sv64[SV_LNL / 2];
@@ -540,7 +907,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             slip_block_sync();
         }
     }
-    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+    if (sv[SV_ERR]) return (early || sv[SV_ERR] >= 6) ? SLIPDEV_INTERNAL : SLIPDEV_GROW_X;    /* after an early commit nothing may fail */
     SLIP_STAMP(3);
 
     /* ---- phase 5: column-window cap, then the pivot search ---- */
@@ -553,12 +920,6 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     auto ent_row  = [&](int t) -> int { return use_tab ? (int) tab[0 * SLIP_TAB_CAP + t] : row_at(t); };
     auto ent_len  = [&](int t) -> int32_t { return use_tab ? (int32_t) tab[1 * SLIP_TAB_CAP + t] : P.xrow[row_at(t)].len; };
     auto ent_bits = [&](int t) -> int { return use_tab ? (int) tab[2 * SLIP_TAB_CAP + t] : P.xrow[row_at(t)].bits; };
-    /* where the digits of a row are: its x row (private), or (rows multiplied straight into L: h == -2) the slab (shared) */
-    auto row_direct = [&](int r) -> int { return P.xrow[r].h == -2; };
-    auto row_digits = [&](int r) -> const dig_t * {
-        const dig_t *X = P.xd + (int64_t) r * P.xcap;
-        return P.xrow[r].h == -2 ? (const dig_t *)(P.Llimbs + *(const int64_t *) X) : X;
-    };
     auto ent_direct = [&](int t) -> int { return use_tab ? (int)(tab[3 * SLIP_TAB_CAP + t] >> 31) : row_direct(row_at(t)); };
     auto ent_digits = [&](int t) -> const dig_t * {
         if (use_tab) return (tab[3 * SLIP_TAB_CAP + t] >> 31) ? (const dig_t *)(P.Llimbs + Lnl0 + (int64_t)(tab[3 * SLIP_TAB_CAP + t] & 0x7FFFFFFFu))
@@ -592,16 +953,22 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         slip_block_sync();
     }
     const int maxdig = sv[SV_MAXDIG];
-    if (P.limb_cap > 0 && ((maxdig + 1) >> 1) > P.limb_cap) return SLIPDEV_WINDOW_END;
+    if (!early && P.limb_cap > 0 && ((maxdig + 1) >> 1) > P.limb_cap) return SLIPDEV_WINDOW_END;
     SLIP_STAMP(12);                                       /* column table built */
 
     /* kind of search: 0 smallest, 1 largest, 2 first nonzero (slip_get_pivot.c:58-155).
      * Lanes order the candidates by (bit length, leading bits); the candidates that tie on
      * that key are compared exactly, ties resolved towards the earlier pattern position. */
-    const int scheme = P.pivot_scheme;
-    const int kind = (scheme == 2) ? 2 : ((scheme == 4 || scheme == 5) ? 1 : 0);
     int best = -1;
-    if (kind != 2 && maxdig < (1 << 18)) {
+    if (early) {
+        /* the pivot is committed: only its place in the pattern is needed */
+        if (tid == 0) sv[SV_TMP] = -1;
+        slip_block_sync();
+        for (int t = tid; t < nL; t += T) if (ent_row(nU + t) == e_pivrow) sv[SV_TMP] = t;
+        slip_block_sync();
+        best = sv[SV_TMP];
+        if (best < 0) return SLIPDEV_INTERNAL;
+    } else if (kind != 2 && maxdig < (1 << 18)) {
         /* one pass: (bit length, leading 40 bits) packed into one key; the candidates that share the best key are
          * compared exactly, ties towards the earlier pattern position (slip_get_smallest_pivot.c:79) */
         auto key_of = [&](int t) -> uint64_t {
@@ -668,48 +1035,18 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     }
     SLIP_STAMP(13);                                       /* smallest / largest candidate known */
     int pivrow = ent_row(nU + best);
-    /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146) */
-    if (scheme == 1 || scheme == 3 || scheme == 4) {
+    /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); an early commit has applied it already */
+    if (!early && (scheme == 1 || scheme == 3 || scheme == 4)) {
         const int pc = pc_col;
         const int diag_ok = pc >= k && ((bm[pc >> 5] >> (pc & 31)) & 1u) && P.xrow[col].tag == tag && P.xrow[col].len != 0;
         if (diag_ok && pivrow != col) {
-            int take = 0, err = 0;
-            if (scheme == 1) take = 1;
-            else if (P.tol_mode == 0) take = 1;
-            else {
-                const int lp_ = slip_abs(P.xrow[pivrow].len), lc_ = slip_abs(P.xrow[col].len);
-                /* tol_m has exactly 53 bits, so tol_m*|den| has 52 or 53 bits more than |den|: most columns
-                 * are decided by the bit lengths alone */
-                const int te0 = P.tol_e;
-                const int bnum_ = (scheme == 3 ? P.xrow[pivrow].bits : P.xrow[col].bits) + (te0 < 0 ? -te0 : 0);
-                const int bden_ = (scheme == 3 ? P.xrow[col].bits : P.xrow[pivrow].bits) + (te0 > 0 ? te0 : 0);
-                if (bnum_ < 52 + bden_) take = 0;
-                else if (bnum_ > 53 + bden_) take = 1;
-                else {
-                    /* exact comparison.  Every wave runs it redundantly in its own scratch.  A row that lives in the L
-                     * slab is shared data: its digits are staged (sc1 loads) into scratch the comparison does not need
-                     * at that point -- the denominator into b1 (free until the last step, when the denominator has
-                     * been consumed), the numerator behind the product in b2. */
-                    const int rn = scheme == 3 ? pivrow : col, rd = scheme == 3 ? col : pivrow;   /* |small|/|diag| or |diag|/|large| >= tol */
-                    const int ln = scheme == 3 ? lp_ : lc_, ldn = scheme == 3 ? lc_ : lp_;
-                    const dig_t *num = P.xd + (int64_t) rn * P.xcap, *den = P.xd + (int64_t) rd * P.xcap;
-                    if (ldn + 2 > wcap) err = 1;
-                    if (!err && row_direct(rd)) { slip_stage_shared(b1, row_digits(rd), ldn); den = b1; }
-                    if (!err && row_direct(rn)) {
-                        if (ldn + 4 + ln > wcap) err = 1;
-                        else { slip_stage_shared(b2 + ldn + 4, row_digits(rn), ln); num = b2 + ldn + 4; }
-                    }
-                    if (!err) {
-                        const int tk = slip_tol_compare_out(P.tol_m, P.tol_e, num, ln, den, ldn, b0, b1, b2, wcap);
-                        if (tk < 0) err = 1; else take = tk;
-                    }
-                }
-            }
+            int err = 0;
+            const int take = diag_rule(pivrow, &err);
             if (err) return SLIPDEV_GROW_X;
             if (take) pivrow = col;
         }
     }
-    const int pivpos = pivrow == col ? pc_col : pat_at(nU + best);   /* pre-swap position (the pattern holds positions), >= k */
+    const int pivpos = early ? e_pivpos : (pivrow == col ? pc_col : pat_at(nU + best));   /* pre-swap position (the pattern holds positions), >= k */
     SLIP_STAMP(4);
 
     /* ---- phase 6: append U(:,k) and L(:,k) (SLIP_LU_factorize.c:226-263) ---- */
@@ -756,7 +1093,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             } else {
                 const int64_t at = Lnz + (e - nUe);
                 const int64_t off = direct ? doff : Lnl + (int64_t)(lalloc + baseL + el);
-                if (at < P.Lcap_nz) { slip_st_i32(&P.Li[at], r); SlipEnt en; en.len = xl; en.bits = xb; en.off = off; slip_st_ent(&P.Le[at], en); }
+                if (at < P.Lcap_nz) { P.Li[at] = r; SlipEnt en; en.len = xl; en.bits = xb; en.off = off; P.Le[at] = en; }   /* plain: published by the release before Lready[k] */
                 if (use_tab && !direct) tab[3 * SLIP_TAB_CAP + pt] = (uint32_t)(off - Lnl);     /* copy destination, flag bit clear */
             }
         }
@@ -764,8 +1101,12 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     }
     const uint64_t totU = baseU, totL = lalloc + baseL;         /* limbs of slab consumed by this column */
     const uint64_t totLexact = baseL + dirL;
-    if (Unz + nUe > P.Ucap_nz || Unl + (int64_t) totU > P.Ucap_nl) return SLIPDEV_GROW_U;
-    if (Lnz + nL > P.Lcap_nz || Lnl + (int64_t) totL > P.Lcap_nl) return SLIPDEV_GROW_L;
+    if (Unz + nUe > P.Ucap_nz || Unl + (int64_t) totU > P.Ucap_nl) return early ? SLIPDEV_INTERNAL : SLIPDEV_GROW_U;
+    if (Lnz + nL > P.Lcap_nz || Lnl + (int64_t) totL > P.Lcap_nl) return early ? SLIPDEV_INTERNAL : SLIPDEV_GROW_L;
+    if (early && (Lnl + (int64_t) totL > slip_ld_i64(&P.Lo[k + 1]) || Unl + (int64_t) totU != slip_ld_i64(&P.Uo[k + 1]))) return SLIPDEV_INTERNAL;   /* the published bounds hold */
+    /* the pivot's record fields, read before the permutation swap below changes what row_perm answers */
+    const int32_t plen = ent_len(pividx);
+    const int pbits = ent_bits(pividx);
     slip_vm_drain();                                     /* the direct rows' and the records' write-through stores have left */
     slip_block_sync();
     SLIP_STAMP(5);
@@ -773,10 +1114,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     /* ---- stage 1: publish the pivot.  Wave 0 moves the pivot's digits to their place in the L slab (if they are
      *      not there yet), builds the pivot record, swaps the permutation and publishes the column pointers; then
      *      the frontier moves and the next column may commit while this one still writes its bulk. ---- */
-    if (wave == 0) {
+    if (wave == 0 && !early) {
         const int found = pividx - nU;                   /* position of the pivot inside L(:,k) */
-        const int32_t plen = ent_len(pividx);
-        const int pbits = ent_bits(pividx);
         const int lp_ = slip_abs(plen);
         int pdirect; int64_t poff;
         if (use_tab) { pdirect = (int)(tab[3 * SLIP_TAB_CAP + pividx] >> 31); poff = Lnl + (int64_t)(tab[3 * SLIP_TAB_CAP + pividx] & 0x7FFFFFFFu); }
@@ -798,6 +1137,15 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             slip_st_i64(&P.Uo[k + 1], Unl + (int64_t) totU); slip_st_i64(&P.Lo[k + 1], Lnl + (int64_t) totL);
             slip_vm_drain();
             slip_st_i32(&st->F, k + 1);
+#ifdef SLIP_PROFILING
+            /* slot 18: from the moment this worker learnt that column k-1 was committed to its own commit */
+            if (t_last_) prof_[18] += slip_clock() - t_last_;
+            {
+                int32_t *tr = P.dbg + 8 * (int64_t) k; const unsigned long long nowc = slip_clock();
+                tr[0] = t_last_ ? (int32_t)(nowc - t_last_) : -1; tr[1] = 0; tr[2] = 0; tr[3] = nrows;
+                tr[4] = (int32_t) tr_sweep_; tr[5] = (int32_t)(nowc - tr_t2_); tr[7] = P.worker;
+            }
+#endif
         }
     }
     SLIP_STAMP(6);
@@ -837,7 +1185,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             dst = (dig_t *)(P.Llimbs + Lnl + (int64_t) tab[3 * SLIP_TAB_CAP + pt]);
         } else {
             const int64_t at = isU ? Unz + e : Lnz + (e - nUe);
-            const int r = isU ? P.Ui[at] : slip_ld_i32(&P.Li[at]);
+            const int r = isU ? P.Ui[at] : slip_ld_i32(&P.Li[at]);                  /* this worker's own records: sc1 loads see its L2 */
             const SlipEnt en = isU ? P.Ue[at] : slip_ld_ent(&P.Le[at]);
             xl = en.len;
             src_shared = row_direct(r);
@@ -847,15 +1195,15 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         }
         const int lw = (slip_abs(xl) + 1) & ~1;
         if (isU) { for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = src_shared ? slip_ld_u32(srcx + c) : srcx[c]; }
-        else     { for (int c = lane; c < lw; c += SLIP_WAVE) slip_st_u32(dst + c, srcx[c]); }
+        else     { for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = srcx[c]; }
     }
     }
     slip_vm_drain();
     slip_block_sync();
     if (tid == 0) {
+        slip_agent_release();                            /* the column's plain stores (L entries, limbs) leave this XCD's L2 */
         slip_agent_add_i32(&P.Lready[k], 1);             /* returning atomic: performed before the advance below reads the flags */
         slip_advance_ready(P, st);
-        const int32_t plen = ent_len(pividx);
         slip_agent_add_u64(&st->c_write, 4ull * (unsigned long long) nE + 8ull * (totU + totLexact) + 8ull * slip_limbs(plen));
         slip_agent_add_u64((unsigned long long *) &st->Lnl_exact, totLexact);
         slip_agent_add_u64((unsigned long long *) &st->Unl_exact, totU);
@@ -952,7 +1300,8 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
     if (sv[SV_ERR]) return SLIPDEV_GROW_X;
 
     /* forward substitution = the sweep over ALL pivot positions (slip_forward_sub.c:61-158) */
-    slip_sweep<FAST, false>(P, st, n, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac);
+    unsigned long long tw_[2] = {0, 0}, tl_ = 0;
+    slip_sweep<FAST, false>(P, st, n, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac, tw_, &tl_);
     slip_block_sync();
     if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
 

@@ -76,6 +76,8 @@ SLIP_DEV void slip_worker_params(SlipParams *Pw, const SlipParams &P, int worker
     Pw->xd = P.xd + (int64_t) worker * P.priv_rows * P.xcap;
     Pw->pat = P.pat + (int64_t) worker * P.priv_rows;
     Pw->rlist = P.rlist + (int64_t) worker * P.priv_rows;
+    Pw->rpos = P.rpos + (int64_t) worker * P.priv_rows;
+    Pw->srow = P.srow + (int64_t) worker * P.priv_rows;
     Pw->gbitmap = P.gbitmap + (int64_t) worker * (P.bitmap_in_lds ? 0 : P.bm_words + 64);
     Pw->gscratch = P.gscratch + (int64_t) worker * (P.scratch_in_lds ? 0 : (int64_t) SLIP_SCRATCH_WAVES * 3 * P.wcap);
 }
@@ -270,7 +272,7 @@ static int32_t default_workers(const slip_hip_factor *f, int32_t xcap)
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     int64_t w = (int64_t) cus * per_cu;
-    const int64_t per_worker = (int64_t) f->n * (16 + 4 * (int64_t) xcap + 8) + 4096;
+    const int64_t per_worker = (int64_t) f->n * (16 + 4 * (int64_t) xcap + 16) + 4096;
     const int64_t budget = 96ll << 30;                                  /* of the 288 GB */
     if (w * per_worker > budget) w = budget / per_worker;
     if (w > f->n) w = f->n;
@@ -298,8 +300,11 @@ static int alloc_x(slip_hip_factor *f, int32_t xcap, int keep_rows)
         if (P->xrow) hipFree(P->xrow);
         if (P->pat) hipFree(P->pat);
         if (P->rlist) hipFree(P->rlist);
-        P->xrow = NULL; P->pat = NULL; P->rlist = NULL;
-        if (dev_alloc(&P->xrow, W * n) || dev_alloc(&P->pat, W * n) || dev_alloc(&P->rlist, W * n)) return SLIP_HIP_OUT_OF_MEMORY;
+        if (P->rpos) hipFree(P->rpos);
+        if (P->srow) hipFree(P->srow);
+        P->xrow = NULL; P->pat = NULL; P->rlist = NULL; P->rpos = NULL; P->srow = NULL;
+        if (dev_alloc(&P->xrow, W * n) || dev_alloc(&P->pat, W * n) || dev_alloc(&P->rlist, W * n) ||
+            dev_alloc(&P->rpos, W * n) || dev_alloc(&P->srow, W * n)) return SLIP_HIP_OUT_OF_MEMORY;
         /* tags start at 0 = "belongs to no column"; tickets count from 1 */
         if (hipMemset(P->xrow, 0, (size_t)(W * n) * sizeof(SlipRow)) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
     }
@@ -347,7 +352,7 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
     hipFree(P->piv); hipFree(P->invd);
     hipFree(P->Lp); hipFree(P->Lo); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
     hipFree(P->Up); hipFree(P->Uo); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
-    hipFree(P->Lready); hipFree(P->pat); hipFree(P->rlist); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg);
+    hipFree(P->Lready); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg);
     hipFree(f->ds); hipFree(f->ident);
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
@@ -457,9 +462,9 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     A_(dev_alloc(&f->dAp, (int64_t) n + 1)); A_(dev_alloc(&f->dAi, onz)); A_(dev_alloc(&f->dAlen, onz));
     A_(dev_alloc(&f->dAoff, onz)); A_(dev_alloc(&f->dAlimbs, ol)); A_(dev_alloc(&f->dq, n));
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 4 * 256));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 8 * (int64_t) n));
     A_(make_ident(f));
-    if (!rc && hipMemset(P->dbg, 0, 4 * 256 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 8 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc && hipMemset(P->piv, 0, (size_t) n * sizeof(SlipPiv)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     /* initial sizes: S->lnz/unz only size the first allocation in the reference too */
     P->Lcap_nz = opt.lnz_hint > 0 ? opt.lnz_hint : 4 * onz + n;
@@ -696,11 +701,11 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     int rc = 0;
 #define A_(call) do { if (!rc) rc = (call); } while (0)
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 4 * 256));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 8 * (int64_t) n));
     A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Lo, (int64_t) n + 1)); A_(dev_alloc(&P->Li, lnz)); A_(dev_alloc(&P->Le, lnz)); A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
     A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Uo, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, unz)); A_(dev_alloc(&P->Ue, unz)); A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
     A_(dev_alloc(&f->ds, 1));
-    if (!rc && hipMemset(P->dbg, 0, 4 * 256 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 8 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc) rc = alloc_x(f, 2 * maxdig + 8, 0);
 #undef A_
 #define UP_(dst, src, bytes) do { if (!rc && (bytes) > 0 && hipMemcpy((void *)(dst), (src), (size_t)(bytes), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR; } while (0)
@@ -886,6 +891,15 @@ extern "C" int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned l
 {
     if (!f || !out24) return SLIP_HIP_INCORRECT_INPUT;
     for (int i = 0; i < 24; i++) out24[i] = f->hs.prof[i];
+    return SLIP_HIP_OK;
+}
+
+/* diagnostic builds: the per-column trace (8 words per column: commit-chain cycles, early flag, candidates computed, rows,
+ * cycles of the sweep after the last frontier wait, of the early pass, of the publish, worker) */
+extern "C" int slip_hip_factor_column_trace(const slip_hip_factor *f, int32_t *out, int32_t ncols)
+{
+    if (!f || !out || ncols <= 0 || ncols > f->n) return SLIP_HIP_INCORRECT_INPUT;
+    CK(hipMemcpy(out, f->P.dbg, (size_t) ncols * 8 * 4, hipMemcpyDeviceToHost));
     return SLIP_HIP_OK;
 }
 

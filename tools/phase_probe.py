@@ -1,26 +1,49 @@
 #!/usr/bin/env python3
-"""Per-phase cycle breakdown from the diagnostic build (libslip_hip_prof.so)."""
+"""Per-phase cycle breakdown of the column workers from the diagnostic build (libslip_hip_prof.so, `make prof`).
+Thread 0 of every worker stamps its phases; the sums over all workers are divided by the columns committed.
+usage: phase_probe.py case[,case...] [workers] [waves]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_case
 import slip_lu_amd as sl
-from slip_lu_amd import _lib
 path = os.path.join(ROOT, "slip_lu_amd", "csrc", "libslip_hip_prof.so")
-names = ["scatter", "sweep", "pattern", "Lhist", "pivot", "offsets", "copy", "commit"]
-for name in sys.argv[1:]:
+SLOTS = {0: "scatter", 1: "sweep(work)", 16: "wait F", 17: "wait F2", 20: "  sweep after last F wait", 2: "position snapshot",
+         21: "early: classify", 22: "early: reduce+candidates", 13: "early: search+diag (or full search)", 6: "stage1 publish",
+         14: "pattern+rank", 8: "hist:stage rho", 9: "hist:classify", 10: "hist:mul+drain",
+         3: "hist:rest", 12: "table+cap", 4: "diag rule", 5: "offsets", 7: "stage2 copy",
+         18: "CRITICAL: F seen -> F stored", 23: "(early commits per column)", 15: "(early candidates computed per column)"}
+workers = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+waves = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+for name in sys.argv[1].split(","):
     entry, fix = load_case(name)
     f = sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], pivot=entry["pivot"],
-                         tol=entry["tol"], limb_cap=entry["cap"], lib_path=path)
+                         tol=entry["tol"], limb_cap=entry["cap"], lib_path=path, workers=workers, waves=waves)
     f.run(entry["kmax"], check=False); f.reset(); f.run(entry["kmax"], check=False)
     i = f.info()
-    out = (C.c_ulonglong * 20)()
+    out = (C.c_ulonglong * 24)()
     f.lib.slip_hip_factor_phase_cycles(f.h, out)
-    tot = (sum(out[:8]) + sum(out[8:11]) + sum(out[12:16])) or 1
-    print(name, "K", i["K"], "kernel_ms %.2f" % i["kernel_ms"], "cycles/col %.0f" % (tot / max(i["K"], 1)),
-          " ".join(f"{n}={100.0 * out[j] / tot:.1f}%" for j, n in enumerate(names)),
-          "| Lhist parts (cycles/col): stage=%d lanes=%d waves=%d wave_items/col=%.1f" % (
-              out[8] / max(i["K"], 1), out[9] / max(i["K"], 1), out[10] / max(i["K"], 1), out[11] / max(i["K"], 1)),
-          "| pivot parts: table=%d keys=%d (rest in pivot) | copy loop: first pass=%d second pass=%d (barrier in copy)" % (
-              out[12] / max(i["K"], 1), out[13] / max(i["K"], 1), out[14] / max(i["K"], 1), out[15] / max(i["K"], 1)))
+    K = max(i["K"], 1)
+    print(f"{name}: K {i['K']} workers {i['workers']} waves {i['waves']} kernel_ms {i['kernel_ms']:.2f} = {1e3 * i['kernel_ms'] / K:.1f} us/col; "
+          f"columns stamped {out[19]}; cycles per committed column:")
+    for slot, label in SLOTS.items():
+        print(f"    {label:36s} {out[slot] / K:12.2f}")
+    if hasattr(f.lib, "slip_hip_factor_column_trace"):
+        import numpy as np
+        tr = np.zeros(8 * i["K"], np.int32)
+        f.lib.slip_hip_factor_column_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        if f.lib.slip_hip_factor_column_trace(f.h, tr.ctypes.data, i["K"]) == 0:
+            tr = tr.reshape(-1, 8)
+            c = tr[:, 0].astype(np.float64)
+            ok = c >= 0
+            print(f"    commit-chain cycles per column: n={ok.sum()} mean {c[ok].mean():.0f} median {np.median(c[ok]):.0f} "
+                  f"p90 {np.percentile(c[ok], 90):.0f} max {c[ok].max():.0f}; early {int(tr[:, 1].sum())} of {len(tr)}")
+            worst = np.argsort(-c)[:12]
+            for kcol in worst:
+                print(f"      col {kcol}: chain {tr[kcol, 0]} early {tr[kcol, 1]} cand {tr[kcol, 2]} rows {tr[kcol, 3]} "
+                      f"sweep-tail+snapshot {tr[kcol, 4]} pass+publish {tr[kcol, 5]} worker {tr[kcol, 7]}")
+            e = tr[:, 1] == 1
+            if e.any():
+                print(f"    early columns: sweep-tail+snapshot mean {tr[e, 4].mean():.0f}, pass+publish mean {tr[e, 5].mean():.0f} "
+                      f"median {np.median(tr[e, 5]):.0f}")
     f.close()
