@@ -72,7 +72,8 @@ typedef struct {
 
 /* mutable across launches; the words other workers poll sit in 128-byte lines of their own */
 typedef struct SlipState {
-    int32_t F;  int32_t padF[31];                   /* commit frontier: columns < F have published their pivot (stage 1) */
+    int32_t F, Fpiv; int32_t padF[30];              /* ONE aligned 64-bit word: the commit frontier (columns < F have published
+                                                       their pivot, stage 1) and, next to it, the pivot row of column F-1 */
     int64_t stop; int64_t padS[15];                 /* (column << 8) | SLIPDEV_* of the first column that cannot commit; min wins */
     int32_t F2; int32_t padF2[31];                  /* ready frontier: columns < F2 have published their L entries (stage 2) */
     int32_t ticket; int32_t padT[31];               /* next column ticket (monotonic across launches)                    */
@@ -137,7 +138,7 @@ typedef struct SlipSolveArgs {
 #define SLIP_WORK_CAP      512
 #define SLIP_WORK_WORDS    (6 * SLIP_WORK_CAP)
 #define SLIP_FAST_CAP       SLIP_TAB_CAP    /* patterns up to this many rows may commit their pivot early */
-#define SLIP_CAND_CAP       SLIP_WORK_CAP   /* ... if no more than this many candidates of either kind need arithmetic */
+#define SLIP_CAND_CAP       256             /* ... if no more than this many rows are candidates */
 #define SLIP_LDS_TAB       (SLIP_LDS_WORK + SLIP_WORK_WORDS)   /* column table: row, len, bits, slab offset per pattern entry */
 #define SLIP_TAB_CAP       1024
 #define SLIP_PAT_CAP       1024     /* a pattern of at most this many entries stays in LDS               */
@@ -323,6 +324,18 @@ SLIP_DEV void slip_st_ent(SlipEnt *p, const SlipEnt &v)
 }
 SLIP_DEV int32_t slip_piv_invlen(const SlipPiv *p) { return slip_ld_i32(&p->invlen); }
 
+/* the frontier word: F in the low half, row_perm[F-1] in the high half (one 8-byte granule, one store, one load) */
+SLIP_DEV int slip_ld_frontier(const SlipState *st, int *pivrow)
+{
+    const uint64_t w = slip_ld_u64((const uint64_t *) &st->F);
+    *pivrow = (int)(uint32_t)(w >> 32);
+    return (int)(uint32_t) w;
+}
+SLIP_DEV void slip_st_frontier(SlipState *st, int F, int pivrow)
+{
+    slip_st_u64((uint64_t *) &st->F, (uint64_t)(uint32_t) F | ((uint64_t)(uint32_t) pivrow << 32));
+}
+
 SLIP_DEV const dig_t *slip_piv_digits(const SlipParams &P, const SlipPiv &pv) { return (const dig_t *)(P.Llimbs + pv.off); }
 
 SLIP_DEV SlipPiv slip_piv_none(void)
@@ -421,7 +434,7 @@ SLIP_DEV void slip_store_small(const SlipParams &P, int i, slip_u128 mag, int sg
  * write-back) after the inverse cache has been extended. */
 SLIP_DEV int slip_ensure_inv(const SlipParams &P, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2)
 {
-    int have = (int) slip_shfl_u32((uint32_t) slip_piv_invlen(&P.piv[p]), 0);
+    int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(&P.piv[p]));
     slip_agent_acquire();                     /* digits below `have` (and, if enough, all we need) are readable now */
     if (have >= want) return 0;
     if (want > P.invcap || want > P.wcap) return 1;
@@ -465,7 +478,7 @@ SLIP_DEV int slip_store_x(const SlipParams &P, int i, const dig_t *q, int W, int
 /* cached inverse of pivot p's odd part to `want` digits, register Newton; b0: scratch for wide shifts */
 template <int D> SLIP_DEV int slip_ensure_inv_reg(const SlipParams &P, int p, int want, dig_t *b0)
 {
-    int have = (int) slip_shfl_u32((uint32_t) slip_piv_invlen(&P.piv[p]), 0);
+    int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(&P.piv[p]));
     if (have >= want) return 0;
     if (want > P.invcap) return 1;
     int target = 2 * have > want ? 2 * have : want;
@@ -813,29 +826,29 @@ SLIP_DEV int slip_cmp_mag(const dig_t *a, int sa, const dig_t *b, int sb, int l)
  * list, so that the pivot search does not read back through memory what this CU has just produced */
 /* what the early commit wants to know about a candidate row it has just multiplied (LDS arrays indexed by the row's
  * place in the worker's row table): the search key, the low limb and the trailing zeros for the pivot record */
-struct SlipCandOut { uint32_t *k0, *k1, *lo0, *lo1, *ctz; int kind; };
+struct SlipCandOut { uint32_t *k0, *k1; uint32_t *inf; dig_t *stage; int slotw, nstage, kind; };
 
 template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const SlipPiv &M, const WR<D> &Y, int r, uint32_t rec3, int64_t off,
-                                                   uint32_t slot_off, uint32_t *ctab, uint32_t *ckeys, int tag, const SlipCandOut *co = (const SlipCandOut *) 0)
+                                                   uint32_t slot_off, uint32_t *ctab, uint32_t *ckeys, int tag, const SlipCandOut *co = (const SlipCandOut *) 0,
+                                                   int li = 0)
 {
     const int len = wr_len<D>(Y);
     /* bulk L data: plain (coalesced) stores; the worker's release fence before Lready[k] publishes them (a 4-byte
      * write-through store is one fabric write per lane: 6x the time of these rows).  A candidate of the early commit may
-     * become the pivot, which later columns read as soon as the frontier moves: written through. */
-    if (co) wr_store_s<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
-    else    wr_store_g<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
+     * become the pivot: its digits are also left in an LDS slot, from where the publishing wave writes them through. */
+    wr_store_g<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
     const uint32_t d1 = len ? wr_digit<D>(Y, len - 1) : 0u;
     const int neg = (int)((rec3 >> 2) & 1u) ^ (M.len < 0);
     const int32_t slen = neg ? -len : len;
     const int bits = len ? 32 * len - slip_clz32(d1) : 0;
     if (co) {
         const uint32_t d2 = len >= 2 ? wr_digit<D>(Y, len - 2) : 0u, d3 = len >= 3 ? wr_digit<D>(Y, len - 3) : 0u;
-        const uint32_t l0 = wr_digit<D>(Y, 0), l1 = wr_digit<D>(Y, 1);
-        int z = 0;
+        const int staged = li < co->nstage;
+        if (staged) {
+            dig_t *sl = co->stage + li * co->slotw;
+            const int lane = slip_lane();
 #pragma unroll
-        for (int q = D - 1; q >= 0; q--) {
-            const uint64_t nz = slip_ballot(Y.d[q] != 0);
-            if (nz) { const int tl_ = slip_ctz64(nz); z = 32 * (64 * q + tl_) + slip_ctz32(slip_readlane(Y.d[q], tl_)); }
+            for (int q = 0; q < D; q++) { const int c = 64 * q + lane; if (c < ((len + 1) & ~1)) sl[c] = Y.d[q]; }
         }
         if (slip_lane() == 0) {
             uint64_t top = ((uint64_t) d1 << 32) | d2;
@@ -845,7 +858,7 @@ template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const Sl
             uint64_t key = ((uint64_t) bits << 40) | (top >> 24);
             if (co->kind == 1) key = ~key;
             co->k0[ti] = (uint32_t) key; co->k1[ti] = (uint32_t)(key >> 32);
-            co->lo0[ti] = l0; co->lo1[ti] = l1; co->ctz[ti] = (uint32_t) z;
+            if (staged) co->inf[ti] |= ((uint32_t)(li + 1) << 26) | (neg ? 0x80000000u : 0u);   /* where the publishing wave finds the digits; the sign */
         }
     }
     if (ctab) {
@@ -885,8 +898,8 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
         if ((w0 & 3u) != 1u || (w1 & 3u) != 1u) break;
         WR<D> Y0, Y1;
         wr_mul_digit2<D>(recs[5 * t + 1], recs[5 * u + 1], Mr, Y0, Y1);
-        slip_mul_row_finish<D>(P, M, Y0, (int) recs[5 * t], w0, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag, co);
-        slip_mul_row_finish<D>(P, M, Y1, (int) recs[5 * u], w1, slab_base + (int64_t) recs[5 * u + 4], recs[5 * u + 4], ctab, ckeys, tag, co);
+        slip_mul_row_finish<D>(P, M, Y0, (int) recs[5 * t], w0, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag, co, t);
+        slip_mul_row_finish<D>(P, M, Y1, (int) recs[5 * u], w1, slab_base + (int64_t) recs[5 * u + 4], recs[5 * u + 4], ctab, ckeys, tag, co, u);
     }
     for (; t < nrows; t += stride) {
         const uint32_t w = recs[5 * t + 3];
@@ -898,7 +911,7 @@ template <int D> SLIP_DEV int slip_mul_rows_reg(const SlipParams &P, const SlipP
             if (lane == 1) A.d[0] = recs[5 * t + 2];
             Y = wr_mul<D>(A, (int)(w & 3u), Mr);
         }
-        slip_mul_row_finish<D>(P, M, Y, (int) recs[5 * t], w, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag, co);
+        slip_mul_row_finish<D>(P, M, Y, (int) recs[5 * t], w, slab_base + (int64_t) recs[5 * t + 4], recs[5 * t + 4], ctab, ckeys, tag, co, t);
     }
     return 0;
 }

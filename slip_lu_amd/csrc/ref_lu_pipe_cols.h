@@ -6,6 +6,11 @@
 /* Spins are bounded by ITERATION counts (each iteration sleeps): a wait that is never answered ends the launch
  * with SLIPDEV_INTERNAL instead of hanging the device. */
 #define SLIP_SPIN_LIMIT 40000000ull
+#ifdef SLIP_PROFILING
+#define SLIP_TR(i) do { if (tid == 0) { const unsigned long long n_ = slip_clock(); trs_[i] = (int32_t)(n_ - trp_); trp_ = n_; } } while (0)
+#else
+#define SLIP_TR(i) do { } while (0)
+#endif
 #define SLIPDEV_ABORTED 100                 /* internal to the kernel: this worker's column can never commit */
 
 SLIP_DEV void slip_raise_stop(SlipState *st, int k, int status) { slip_agent_min_i64(&st->stop, ((int64_t) k << 8) | (int64_t) status); }
@@ -20,8 +25,9 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k)
         int res;
         unsigned long long spins = 0;
         for (;;) {
-            const int F = slip_ld_i32(&st->F);
-            if (F >= need) { res = F; break; }
+            int pr;
+            const int F = slip_ld_frontier(st, &pr);
+            if (F >= need) { res = F; sv[SV_TMP3] = pr; break; }       /* pr = row_perm[F-1], for free */
             const int64_t stop = slip_ld_i64(&st->stop);
             if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             /* the further from its turn, the longer between polls: the frontier word is one line for the whole chip */
@@ -43,7 +49,7 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k)
 SLIP_DEV int slip_advance_ready(const SlipParams &P, SlipState *st)
 {
     int f2 = slip_agent_add_i32(&st->F2, 0);
-    const int F = slip_ld_i32(&st->F);
+    int pr_; const int F = slip_ld_frontier(st, &pr_);
     while (f2 < F && slip_agent_add_i32(&P.Lready[f2], 0) != 0) {
         const int seen = slip_agent_cas_i32(&st->F2, f2, f2 + 1);
         f2 = seen == f2 ? f2 + 1 : seen;
@@ -74,14 +80,18 @@ SLIP_DEV int slip_wait_ready(const SlipParams &P, SlipState *st, uint32_t *lds, 
 }
 
 /* append this lane's newly discovered row to the worker's row list (slots per wave: one LDS atomic per wave) */
-SLIP_DEV void slip_rlist_push(const SlipParams &P, volatile int32_t *sv, int has, int row)
+SLIP_DEV void slip_rlist_push(const SlipParams &P, volatile int32_t *sv, uint32_t *lds, int has, int row)
 {
     const int lane = slip_lane();
     const uint64_t nm = slip_ballot(has);
     int base = 0;
     if (lane == 0 && nm) base = slip_atomic_add_i32((int32_t *) &sv[SV_NROWS], slip_popc64(nm));
-    base = (int) slip_shfl_u32((uint32_t) base, 0);
-    if (has) P.rlist[base + slip_popc64(nm & ((1ull << lane) - 1ull))] = row;
+    base = (int) slip_bcast0_u32((uint32_t) base);
+    if (has) {
+        const int at = base + slip_popc64(nm & ((1ull << lane) - 1ull));
+        P.rlist[at] = row;
+        if (at < SLIP_TAB_CAP) lds[SLIP_LDS_TAB + at] = (uint32_t) row;      /* short patterns are listed in LDS as well */
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -128,14 +138,24 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
 #endif
             int Fn = slip_wait_frontier(st, lds, Fl + 1, k);
 #ifdef SLIP_PROFILING
-            *t_last = slip_clock(); t_wait[0] += *t_last - tw0_;
+            *t_last = slip_clock(); t_wait[0] += *t_last - tw0_; t_wait[2] = slip_realtime();
 #endif
             if (Fn < 0) return 1;
+            const int Fseen = Fn, prow = sv[SV_TMP3];       /* the frontier word carried row_perm[Fseen-1] */
             if (Fn > k) Fn = k;
-            for (int c = Fl + tid; c < Fn; c += T) {
-                const int r = slip_ld_i32(&P.row_perm[c]);
-                if (P.xrow[r].tag == tag) slip_atomic_or_u32(&bm[c >> 5], 1u << (c & 31));
-            }
+            const int nr = sv[SV_NROWS];
+            if (nr <= SLIP_TAB_CAP) {
+                /* the rows of the pattern are listed in LDS: every thread looks at its share for each new pivot row */
+                const uint32_t *lrow = lds + SLIP_LDS_TAB;
+                for (int c = Fl; c < Fn; c++) {
+                    const int r = c == Fseen - 1 ? prow : slip_ld_i32(&P.row_perm[c]);
+                    for (int t = tid; t < nr; t += T) if ((int) lrow[t] == r) slip_atomic_or_u32(&bm[c >> 5], 1u << (c & 31));
+                }
+            } else
+                for (int c = Fl + tid; c < Fn; c += T) {
+                    const int r = slip_ld_i32(&P.row_perm[c]);
+                    if (P.xrow[r].tag == tag) slip_atomic_or_u32(&bm[c >> 5], 1u << (c & 31));
+                }
             if (tid == 0) sv[SV_F] = Fn;
             continue;
         }
@@ -254,7 +274,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
                 if (!done) { queue = 1; qi = i; }
                 } while (0);
                 /* new rows join the row list; a row that is pivotal below the frontier becomes a later source */
-                slip_rlist_push(P, sv, fresh, fi);
+                slip_rlist_push(P, sv, lds, fresh, fi);
                 if (fresh) {
                     const int pos = slip_ld_i32(&P.pinv[fi]);
                     if (pos < Fl) slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
@@ -263,7 +283,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
                 const uint64_t qm = slip_ballot(queue);
                 int qbase = 0;
                 if (lane == 0 && qm) qbase = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(qm));
-                qbase = (int) slip_shfl_u32((uint32_t) qbase, 0);
+                qbase = (int) slip_bcast0_u32((uint32_t) qbase);
                 if (queue) {
                     const int at = qbase + slip_popc64(qm & ((1ull << lane) - 1ull));
                     wl[2 * at] = (uint32_t)(m - m0); wl[2 * at + 1] = (uint32_t) qi;
@@ -364,7 +384,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         sv64[SV_LALLOC / 2] = 0; sv64[SV_LEXACT / 2] = 0;
         /* the ready frontier first: it never passes the commit frontier, also not between the two loads */
         sv[SV_F2] = slip_ld_i32(&st->F2);
-        int F = slip_ld_i32(&st->F);
+        int pr_; int F = slip_ld_frontier(st, &pr_);
         sv[SV_F] = F < k ? F : k;
     }
     slip_block_sync();
@@ -393,19 +413,23 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             P.xrow[row] = r;
             c_read += 4 + 8 * (unsigned long long)((la + 1) >> 1);
         }
-        slip_rlist_push(P, sv, have, row);
+        slip_rlist_push(P, sv, lds, have, row);
     }
     slip_block_sync();
     if (sv[SV_ERR]) return SLIPDEV_GROW_X;
     SLIP_STAMP(0);
 
     /* ---- phase 2: ascending sweep over the pivotal part of the pattern, ahead of the frontier ---- */
-    unsigned long long t_wait_[2] = {0, 0}, t_last_ = 0;
+    unsigned long long t_wait_[3] = {0, 0, 0}, t_last_ = 0;
+#ifdef SLIP_PROFILING
+    int32_t trs_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long trp_ = 0;
+#endif
     if (slip_sweep<FAST, true>(P, st, k, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac, t_wait_, &t_last_)) return SLIPDEV_ABORTED;
     slip_block_sync();
     if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
     SLIP_STAMP(1);
 #ifdef SLIP_PROFILING
+    trp_ = t_last_ ? t_last_ : slip_clock(); SLIP_TR(0);        /* 0: sweep tail */
     /* slot 1: the sweep's own work; 16/17: waiting for the commit / ready frontier; 19: columns counted */
     if (tid == 0) { prof_[1] -= t_wait_[0] + t_wait_[1]; prof_[16] += t_wait_[0]; prof_[17] += t_wait_[1]; prof_[19] += 1;
                     if (t_last_) prof_[20] += t_prev_ - t_last_; }      /* 20: sweep work after the last frontier wait (on the commit chain) */
@@ -420,36 +444,49 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     const bool small = nrows <= SLIP_TAB_CAP;
     uint32_t *f_row = lds + SLIP_LDS_TAB, *f_pos = f_row + SLIP_TAB_CAP, *f_inf = f_pos + SLIP_TAB_CAP, *f_aux = f_inf + SLIP_TAB_CAP;
     uint32_t *f_k0 = lds + SLIP_LDS_KEYS, *f_k1 = f_k0 + SLIP_PAT_CAP;                    /* search keys of exact candidates */
-    uint32_t *c_lo0 = lds + SLIP_LDS_PAT, *c_lo1 = lds + SLIP_LDS_ROWS, *c_ctz = lds + SLIP_LDS_DIROFF;   /* free until phase 3c */
     const int scheme = P.pivot_scheme;
     const int kind = (scheme == 2) ? 2 : ((scheme == 4 || scheme == 5) ? 1 : 0);   /* 0 smallest, 1 largest, 2 first nonzero */
     const bool try_early = k >= 1 && nrows <= SLIP_FAST_CAP;
+    /* the first round of loads of the commit chain: everything is issued before anything is waited for -- this thread's
+     * row (its position and state), then rho[k-1]'s record, and the column cursors by six lanes of the last wave */
+    int r0_ = 0, pos0_ = 0; SlipRow xr0_; xr0_.len = 0; xr0_.h = 0; xr0_.bits = 0; xr0_.tag = 0;
+    if (tid < nrows) {
+        r0_ = small ? (int) f_row[tid] : P.rlist[tid];
+        pos0_ = slip_ld_i32(&P.pinv[r0_]);
+        if (try_early) xr0_ = P.xrow[r0_];
+    }
     SlipPiv M = slip_piv_none();
     if (k >= 1) M = slip_ld_piv(&P.piv[k - 1]);
+    {
+        const int q_ = tid - (T - 8);
+        if (q_ == 0) sv64[SV_LNZ / 2] = slip_ld_i64(&P.Lp[k]);
+        else if (q_ == 1) sv64[SV_LNL / 2] = slip_ld_i64(&P.Lo[k]);
+        else if (q_ == 2) sv64[SV_UNZ / 2] = slip_ld_i64(&P.Up[k]);
+        else if (q_ == 3) sv64[SV_UNL / 2] = slip_ld_i64(&P.Uo[k]);
+        else if (q_ == 4) sv[SV_TMP3] = slip_ld_i32(&P.pinv[col]);        /* position of the "diagonal" row: fixed until this column's swap */
+        else if (q_ == 5) sv[SV_TMP] = slip_ld_i32(&P.row_perm[k]);       /* the row the pivot will change places with                    */
+        else if (q_ == 6) { sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_LISTN] = 0; }
+    }
     const int lm = slip_abs(M.len), brho = M.bits;
     const int slot = (lm + 3) >> 1;
-    if (tid == 0) {
-        sv64[SV_LNZ / 2] = slip_ld_i64(&P.Lp[k]); sv64[SV_LNL / 2] = slip_ld_i64(&P.Lo[k]);
-        sv64[SV_UNZ / 2] = slip_ld_i64(&P.Up[k]); sv64[SV_UNL / 2] = slip_ld_i64(&P.Uo[k]);
-        sv[SV_TMP3] = slip_ld_i32(&P.pinv[col]);        /* position of the "diagonal" row: fixed until this column's swap */
-        sv[SV_TMP] = slip_ld_i32(&P.row_perm[k]);       /* the row the pivot will change places with                    */
-        sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_LISTN] = 0;
-    }
     /* class of a row for the early commit: 0 not a candidate (pivotal or zero), 1 exact (value at level k-1 in its x
      * row), 2 pending A (one limb times the long pivot -> straight into the L slab), 3 pending B (wave item) */
     uint64_t ulimbs = 0, lbound = 0; int nUc = 0, bad = 0, maxub = 0; uint32_t best_b = kind == 1 ? 0u : 0xFFFFFFFFu;
     volatile int32_t *acnt = &sv[SV_ACNT];               /* zero since the column started: no barrier needed before the first slot is drawn */
     for (int t0 = 0; t0 < nrows; t0 += T) {
         const int t = t0 + tid;
-        int cls = 0, ub = 0, isA = 0, r = 0, pos = 0;
+        int cls = 0, ub = 0, isA = 0, r = 0, pos = 0; uint32_t asgn = 0;
         if (t < nrows) {
-            r = P.rlist[t];
-            pos = slip_ld_i32(&P.pinv[r]);
+            if (t0 == 0) { r = r0_; pos = pos0_; }            /* loaded above, with everything else */
+            else {
+                r = small ? (int) f_row[t] : P.rlist[t];      /* short patterns: listed in LDS since their discovery */
+                pos = slip_ld_i32(&P.pinv[r]);
+            }
             slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
-            if (small) { f_row[t] = (uint32_t) r; f_pos[t] = (uint32_t) pos; } else P.rpos[t] = pos;
+            if (small) f_pos[t] = (uint32_t) pos; else P.rpos[t] = pos;
         }
         if (try_early && t < nrows) {
-            const SlipRow xr = P.xrow[r];
+            const SlipRow xr = t0 == 0 ? xr0_ : P.xrow[r];
             if (pos < k) { ulimbs += (uint64_t) slip_limbs(xr.len); nUc++; if (xr.bits > maxub) maxub = xr.bits; }
             else if (xr.len == 0) cls = 0;
             else if (xr.h >= k - 1) {
@@ -462,16 +499,15 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 if (slip_abs(xr.len) <= 2 && slip_history_small(P, xr, xv, M, xr.h, &y, &ys)) {
                     slip_store_small(P, r, y, ys, k - 1, tag);        /* now at level k-1 */
                     cls = 1; ub = slip_bits128(y); lbound += (uint64_t)((((ub + 31) >> 5) + 1) >> 1);
-                    /* the lane has the value: search key, low limb and trailing zeros from registers */
+                    /* the lane has the value: search key from registers */
                     const uint64_t top = ub ? (uint64_t)((y << (128 - ub)) >> 64) : 0ull;
                     uint64_t key = ((uint64_t) ub << 40) | (top >> 24);
                     if (kind == 1) key = ~key;
                     f_k0[t] = (uint32_t) key; f_k1[t] = (uint32_t)(key >> 32);
-                    c_lo0[t] = (uint32_t) y; c_lo1[t] = (uint32_t)((uint64_t) y >> 32);
-                    const uint64_t ylo = (uint64_t) y, yhi = (uint64_t)(y >> 64);
-                    c_ctz[t] = (uint32_t)(ylo ? slip_ctz64(ylo) : 64 + slip_ctz64(yhi));
                 } else if (xr.h < 0 && slip_abs(xr.len) <= 2 && lm + 2 <= P.xcap && lm + 2 <= 256) {
                     cls = 2; isA = 1; ub = xr.bits + brho;
+                    f_k0[t] = (uint32_t) xv; f_k1[t] = (uint32_t)(xv >> 32);       /* the one-limb value, for the candidate record (the key comes later) */
+                    asgn = ((uint32_t) slip_abs(xr.len) << 12) | (xr.len < 0 ? 1u << 14 : 0u);
                 } else {
                     cls = 3;
                     int bh = 0, zh = 0;
@@ -491,10 +527,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             const uint64_t am = slip_ballot(isA);
             int abase = 0;
             if (lane == 0 && am) abase = slip_atomic_add_i32((int32_t *) acnt, slip_popc64(am));
-            abase = (int) slip_shfl_u32((uint32_t) abase, 0);
+            abase = (int) slip_bcast0_u32((uint32_t) abase);
             if (isA) {
                 const int si = abase + slip_popc64(am & ((1ull << lane) - 1ull));
-                f_aux[t] = (uint32_t) si;
+                f_aux[t] = (uint32_t) si | asgn;                  /* slot (10 bits), digits of the value (12-13), its sign (14) */
                 (P.xd + (int64_t) r * P.xcap)[2] = (uint32_t) si;
             }
             if (t < nrows) {
@@ -508,11 +544,13 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             }
         }
     }
+    SLIP_TR(1);                                              /* 1: loads + classification */
     /* rho[k-1]'s digits for the candidate multiplies: staged in LDS while the reduction below runs */
     const bool BMs = SCR_LDS && lm <= wcap;
     dig_t *Ms = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + nw * 3 * wcap : (dig_t *) 0;
     if (try_early && BMs) { const dig_t *Mg = slip_piv_digits(P, M); for (int c = tid; c < lm; c += T) Ms[c] = slip_ld_u32(Mg + c); }
     slip_block_sync();
+    SLIP_TR(2);                                              /* 2: rho staging + barrier */
     const int pc_col = sv[SV_TMP3];
 #ifdef SLIP_PROFILING
     const unsigned long long tr_t2_ = slip_clock();
@@ -565,31 +603,29 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
      * first, otherwise the column takes the complete path below (everything computed, then the search, then the commit). */
     int early = 0, e_pivrow = -1, e_pivpos = -1;
     if (try_early) {
-        /* one fused reduction: sums (U limbs, L limb bound, pivotal rows), maxima (trouble flag, longest bound), best bound */
-        uint64_t red_u = ulimbs, red_l = lbound; uint32_t red_n = (uint32_t) nUc, red_bad = (uint32_t) bad, red_mx = (uint32_t) maxub;
-        uint32_t red_b = kind == 1 ? 0xFFFFFFFFu - best_b : best_b;           /* smaller is better in every kind */
-        for (int d = 32; d >= 1; d >>= 1) {
-            red_u += slip_shfl_u64(red_u, lane ^ d); red_l += slip_shfl_u64(red_l, lane ^ d);
-            red_n += slip_shfl_u32(red_n, lane ^ d);
-            { const uint32_t o = slip_shfl_u32(red_bad, lane ^ d); if (o > red_bad) red_bad = o; }
-            { const uint32_t o = slip_shfl_u32(red_mx, lane ^ d); if (o > red_mx) red_mx = o; }
-            { const uint32_t o = slip_shfl_u32(red_b, lane ^ d); if (o < red_b) red_b = o; }
-        }
-        if (lane == 0) {
-            scan_tmp[4 * wave] = red_u; scan_tmp[4 * wave + 1] = red_l;
-            scan_tmp[4 * wave + 2] = (uint64_t) red_n | ((uint64_t) red_bad << 32);
-            scan_tmp[4 * wave + 3] = (uint64_t) red_mx | ((uint64_t) red_b << 32);
+        /* one fused reduction: sums (U limbs, L limb bound, pivotal rows), maxima (trouble flag, longest bound), best bound.
+         * Inside a wave with DPP row shifts (limb counts of a column stay far below 2^32), across the waves through LDS. */
+        {
+            const uint32_t w_u = slip_wave_sum_u32((uint32_t) ulimbs), w_l = slip_wave_sum_u32((uint32_t) lbound);
+            const uint32_t w_n = slip_wave_sum_u32((uint32_t) nUc), w_bad = slip_wave_max_u32((uint32_t) bad);
+            const uint32_t w_mx = slip_wave_max_u32((uint32_t) maxub);
+            const uint32_t w_b = slip_wave_min_u32(kind == 1 ? 0xFFFFFFFFu - best_b : best_b);     /* smaller is better in every kind */
+            if (lane == 0) {
+                uint32_t *rp = (uint32_t *) scan_tmp + 8 * wave;
+                rp[0] = w_u; rp[1] = w_l; rp[2] = w_n; rp[3] = w_bad; rp[4] = w_mx; rp[5] = w_b;
+            }
         }
         slip_block_sync();
         uint64_t U_l = 0, L_b = 0; uint32_t nUc_all = 0, bad_all = 0, maxub_all = 0, bb = 0xFFFFFFFFu;
         for (int w = 0; w < nw; w++) {
-            U_l += scan_tmp[4 * w]; L_b += scan_tmp[4 * w + 1];
-            const uint64_t a2 = scan_tmp[4 * w + 2], a3 = scan_tmp[4 * w + 3];
-            nUc_all += (uint32_t) a2; if ((uint32_t)(a2 >> 32) > bad_all) bad_all = (uint32_t)(a2 >> 32);
-            if ((uint32_t) a3 > maxub_all) maxub_all = (uint32_t) a3;
-            if ((uint32_t)(a3 >> 32) < bb) bb = (uint32_t)(a3 >> 32);
+            const uint32_t *rp = (const uint32_t *) scan_tmp + 8 * w;
+            U_l += rp[0]; L_b += rp[1]; nUc_all += rp[2];
+            if (rp[3] > bad_all) bad_all = rp[3];
+            if (rp[4] > maxub_all) maxub_all = rp[4];
+            if (rp[5] < bb) bb = rp[5];
         }
         SLIP_STAMP(21);                                     /* early: classification + reduction */
+        SLIP_TR(3);                                         /* 3: wave reduce + barrier + combine */
         if (bb == 0xFFFFFFFFu) return SLIPDEV_SINGULAR;      /* no nonzero non-pivotal row at all (slip_get_smallest_pivot.c:93-96) */
         const int nA = *acnt;
         const uint32_t bestb = kind == 1 ? 0xFFFFFFFFu - bb : bb;
@@ -604,19 +640,23 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         if (Unz_ + (int) nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t) Ub_total > P.Ucap_nl) ok = 0;
         if (P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) ok = 0;  /* the window may end here: decide on exact values */
         const int diag_cand = (scheme == 1 || scheme == 3 || scheme == 4) && pc_col >= k && P.xrow[col].tag == tag && P.xrow[col].len != 0;
-        uint32_t *wlB = work, *wlA = work + SLIP_WORK_CAP;
-        volatile int32_t *cntA = &sv[SV_CNT0 + 1], *cntB = &sv[SV_CNT0 + 2];
+        /* lists in the work area: class-B candidates (rows), all candidates (table indices), class-A candidates (5-word records) */
+        uint32_t *wlB = work, *cl = work + SLIP_CAND_CAP, *wlA = work + 2 * SLIP_CAND_CAP;
+        volatile int32_t *cntA = &sv[SV_CNT0 + 1], *cntB = &sv[SV_CNT0 + 2], *cntC = &sv[SV_LISTN];
+        /* a candidate's product is also left in LDS (slots over the areas phase 3c fills later) for the publishing wave */
+        dig_t *stage = lds + SLIP_LDS_PAT;
+        const int slotw = (lm + 5) & ~1;                      /* even: the low limb is read as one aligned 64-bit word */
+        const int nstage = (3 * SLIP_PAT_CAP) / slotw < 30 ? (3 * SLIP_PAT_CAP) / slotw : 30;   /* the slot number travels in 5 bits of f_inf */
         if (ok) {
-            /* pass 2: the candidates.  Pending ones are listed for the waves: class A -> 5-word records (one limb times
+            /* marking: the candidates.  Pending ones are listed for the waves: class A -> 5-word records (one limb times
              * rho[k-1] straight into its slot of the L slab), class B -> history items. */
             for (int t0 = 0; t0 < nrows; t0 += T) {
                 const int t = t0 + tid;
-                int wantA = 0, wantB = 0, r = 0;
+                int wantA = 0, wantB = 0, cand = 0, r = 0;
                 if (t < nrows) {
                     const uint32_t inf = f_inf[t];
                     const int cls = (int)(inf & 3u), ub = (int)(inf >> 2);
                     r = (int) f_row[t];
-                    int cand = 0;
                     if (cls) {
                         const int lb = cls == 1 ? ub : (cls == 2 ? ub - 1 : (ub > 2 ? ub - 2 : 1));
                         if (kind == 0) cand = (uint32_t) lb <= bestb;
@@ -624,49 +664,52 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                         else cand = f_pos[t] == bestb;
                         if (diag_cand && r == col) cand = 1;
                     }
-                    f_inf[t] = inf | (cand ? 0x80000000u : 0u);         /* bit lengths stay far below 2^29 */
                     wantA = cand && cls == 2; wantB = cand && cls == 3;
                 }
-                const uint64_t mA = slip_ballot(wantA), mB = slip_ballot(wantB);
-                int bA = 0, bB = 0;
+                const uint64_t mA = slip_ballot(wantA), mB = slip_ballot(wantB), mC = slip_ballot(cand);
+                int bA = 0, bB = 0, bC = 0;
                 if (lane == 0) {
                     if (mA) bA = slip_atomic_add_i32((int32_t *) cntA, slip_popc64(mA));
                     if (mB) bB = slip_atomic_add_i32((int32_t *) cntB, slip_popc64(mB));
+                    if (mC) bC = slip_atomic_add_i32((int32_t *) cntC, slip_popc64(mC));
                 }
-                bA = (int) slip_shfl_u32((uint32_t) bA, 0); bB = (int) slip_shfl_u32((uint32_t) bB, 0);
+                bA = (int) slip_bcast0_u32((uint32_t) bA); bB = (int) slip_bcast0_u32((uint32_t) bB); bC = (int) slip_bcast0_u32((uint32_t) bC);
                 const uint64_t below = (1ull << lane) - 1ull;
+                if (cand) { const int at = bC + slip_popc64(mC & below); if (at < SLIP_CAND_CAP) cl[at] = (uint32_t) t; }
                 if (wantA) {
                     const int at = bA + slip_popc64(mA & below);
                     if (at < SLIP_CAND_CAP) {
-                        const SlipRow xr = P.xrow[r];
-                        const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
-                        wlA[5 * at] = (uint32_t) r; wlA[5 * at + 1] = (uint32_t) xv; wlA[5 * at + 2] = (uint32_t)(xv >> 32);
-                        wlA[5 * at + 3] = ((uint32_t) t << 3) | (xr.len < 0 ? 4u : 0u) | (uint32_t) slip_abs(xr.len);
-                        wlA[5 * at + 4] = f_aux[t] * (uint32_t) slot;
+                        const uint32_t ax = f_aux[t];
+                        wlA[5 * at] = (uint32_t) r; wlA[5 * at + 1] = f_k0[t]; wlA[5 * at + 2] = f_k1[t];
+                        wlA[5 * at + 3] = ((uint32_t) t << 3) | ((ax >> 14) & 1u ? 4u : 0u) | ((ax >> 12) & 3u);
+                        wlA[5 * at + 4] = (ax & 0x3FFu) * (uint32_t) slot;
                     }
                 } else if (wantB) { const int at = bB + slip_popc64(mB & below); if (at < SLIP_CAND_CAP) wlB[at] = (uint32_t) r; }
             }
             slip_block_sync();
-            if (*cntA > SLIP_CAND_CAP || *cntB > SLIP_CAND_CAP) ok = 0;          /* too many candidates for the lists: the complete path */
+            if (*cntC > SLIP_CAND_CAP) ok = 0;                /* too many candidates for the lists: the complete path */
+            SLIP_TR(4);                                       /* 4: marking + barrier */
         }
         if (ok) {
-            const int ncA = *cntA, ncB = *cntB;
+            const int ncA = *cntA, ncB = *cntB, ncand = *cntC;
             if (ncA > 0) {
-                const SlipCandOut co = { f_k0, f_k1, c_lo0, c_lo1, c_ctz, kind };
+                const SlipCandOut co = { f_k0, f_k1, f_inf, stage, slotw, nstage, kind };
                 const int e = slip_mul_rows_any(P, M, BMs ? Ms : slip_piv_digits(P, M), BMs ? 0 : 1, wlA, wave, nw, ncA, Lnl_, (uint32_t *) 0, (uint32_t *) 0, tag, &co);
                 if (e && lane == 0) sv[SV_ERR] = 1;
+                /* a product that is read back from the slab (not staged, or the diagonal rule looks at it) must have landed */
+                if (ncA > nstage || diag_cand) slip_vm_drain();
             }
-            slip_vm_drain();                                  /* the candidates' write-through stores have left before anyone publishes */
             slip_block_sync();
             if (ncB > 0) slip_drain(P, lds, 2, 0, 0, k, 0, ncB, wlB, b0, b1, b2);
             if (sv[SV_ERR]) return SLIPDEV_INTERNAL;          /* the bounds said this could not happen */
             SLIP_STAMP(22);                                   /* early: candidate lists and arithmetic */
-            /* pass 3: exact search among the candidates (all exact now), slip_get_pivot.c:58-155: (bit length, leading
-             * bits) keys; the candidates that tie on the best key are compared exactly, then by position */
+            SLIP_TR(5);                                       /* 5: candidate multiplies + barrier */
+            /* the exact search among the candidates (all exact now), slip_get_pivot.c:58-155: (bit length, leading bits)
+             * keys; the candidates that tie on the best key are compared exactly, then by position.  Every wave does the
+             * whole (short) search by itself: lanes = candidates, no workgroup barrier. */
             auto key_of = [&](int t) -> uint64_t {
                 if (kind == 2) return (uint64_t) f_pos[t];
-                const uint32_t inf = f_inf[t];
-                const int cls = (int)(inf & 3u);
+                const int cls = (int)(f_inf[t] & 3u);
                 uint64_t key = (uint64_t) f_k0[t] | ((uint64_t) f_k1[t] << 32);
                 if (cls == 3 || (cls == 1 && key == ~0ull)) {          /* value produced by a wave item / final before: key from its digits */
                     const int r = (int) f_row[t];
@@ -677,64 +720,71 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 }
                 return key;
             };
-            uint64_t k1 = ~0ull;
-            for (int t = tid; t < nrows; t += T) {
-                if (!(f_inf[t] >> 31)) continue;
-                const uint64_t v = key_of(t);
-                f_k0[t] = (uint32_t) v; f_k1[t] = (uint32_t)(v >> 32);
-                if (v < k1) k1 = v;
+            uint64_t mk = ~0ull;
+            for (int c0 = 0; c0 < ncand; c0 += SLIP_WAVE) {
+                const int c = c0 + lane;
+                const uint64_t key = c < ncand ? key_of((int) cl[c]) : ~0ull;
+                /* 64-bit minimum over the wave: the high words first, the low words among the lanes that hold the minimum */
+                const uint32_t mh = slip_wave_min_u32((uint32_t)(key >> 32));
+                const uint32_t ml = slip_wave_min_u32((uint32_t)(key >> 32) == mh ? (uint32_t) key : 0xFFFFFFFFu);
+                const uint64_t wm = ((uint64_t) mh << 32) | ml;
+                if (wm < mk) mk = wm;
             }
-            const uint64_t mk = slip_block_min_u64(k1, scan_tmp);
-            uint32_t *tl = work;                              /* tie list: table indices */
-            for (int t = tid; t < nrows; t += T) {
-                if (!(f_inf[t] >> 31)) continue;
-                if (((uint64_t) f_k0[t] | ((uint64_t) f_k1[t] << 32)) != mk) continue;
-                const int at = slip_atomic_add_i32((int32_t *) &sv[SV_LISTN], 1);
-                if (at < SLIP_WORK_WORDS) tl[at] = (uint32_t) t;
-            }
-            slip_block_sync();
-            const int nc = sv[SV_LISTN];
             int bt = -1;
             const int kbits = kind == 2 ? 0 : (int)((kind == 0 ? mk : ~mk) >> 40);
-            for (int c = 0; c < nc; c++) {                    /* every wave performs the same reduction (wave-uniform, reads only) */
-                const int t = (int) tl[c];
-                if (bt < 0) { bt = t; continue; }
-                const int rb = (int) f_row[bt], rt = (int) f_row[t];
-                int cmp = 0;
-                if (kbits > 40)      /* at most 40 bits: equal keys are equal values */
-                    cmp = slip_cmp_mag(row_digits(rb), row_direct(rb), row_digits(rt), row_direct(rt), slip_abs(P.xrow[rt].len));
-                if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && f_pos[t] < f_pos[bt])) bt = t;
+            for (int c0 = 0; c0 < ncand; c0 += SLIP_WAVE) {
+                const int c = c0 + lane;
+                const int t = c < ncand ? (int) cl[c] : -1;
+                uint64_t tie = slip_ballot(t >= 0 && key_of(t) == mk);
+                while (tie) {
+                    const int l = slip_ctz64(tie); tie &= tie - 1;
+                    const int tt = (int) slip_readlane((uint32_t) t, l);
+                    if (bt < 0) { bt = tt; continue; }
+                    const int rb = (int) f_row[bt], rt = (int) f_row[tt];
+                    int cmp = 0;
+                    if (kbits > 40)      /* at most 40 bits: equal keys are equal values */
+                        cmp = slip_cmp_mag(row_digits(rb), row_direct(rb), row_digits(rt), row_direct(rt), slip_abs(P.xrow[rt].len));
+                    if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && f_pos[tt] < f_pos[bt])) bt = tt;
+                }
             }
             if (bt < 0) return SLIPDEV_INTERNAL;
             e_pivrow = (int) f_row[bt]; e_pivpos = (int) f_pos[bt];
+            int stg = (int)((f_inf[bt] >> 26) & 31u) - 1;     /* LDS slot of the pivot's digits, or -1 */
             /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); col's value is exact: it was a candidate */
             if (diag_cand && e_pivrow != col) {
                 int derr = 0;
                 const int take = diag_rule(e_pivrow, &derr);
                 if (derr) return SLIPDEV_GROW_X;
-                if (take) { e_pivrow = col; e_pivpos = pc_col; }
+                if (take) { e_pivrow = col; e_pivpos = pc_col; stg = -1; }
             }
             SLIP_STAMP(13);
-            /* stage 1, early: the pivot's digits to the L slab (its class-A slot, or the reserved slot behind those),
-             * the pivot record, the permutation swap, the column pointers (limb offsets from the bounds), the frontier */
-            const SlipRow pxr = P.xrow[e_pivrow];
-            const int pdirect = pxr.h == -2;
-            const int64_t poff = pdirect ? *(const int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) : Lnl_ + (int64_t) nA * slot;
+            SLIP_TR(6);                                       /* 6: search + diag */
+            /* stage 1, early: the pivot's digits written through to the L slab (its class-A slot, or the reserved slot behind
+             * those), the pivot record, the permutation swap, the column pointers (limb offsets from the bounds), ONE
+             * drain, the frontier */
+            SlipRow pxr; int pdirect; int64_t poff;
+            if (stg >= 0) {
+                /* a class-A candidate multiplied a moment ago: everything about it is in LDS */
+                uint64_t key = (uint64_t) f_k0[bt] | ((uint64_t) f_k1[bt] << 32);
+                if (kind == 1) key = ~key;
+                pxr.bits = (int)(key >> 40);
+                const int len_ = (pxr.bits + 31) >> 5;
+                pxr.len = (f_inf[bt] >> 31) ? -len_ : len_; pxr.h = -2; pxr.tag = tag;
+                pdirect = 1; poff = Lnl_ + (int64_t)(f_aux[bt] & 0x3FFu) * slot;
+            } else {
+                pxr = P.xrow[e_pivrow];
+                pdirect = pxr.h == -2;
+                poff = pdirect ? *(const int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) : Lnl_ + (int64_t) nA * slot;
+            }
             const uint64_t plimbs = (uint64_t) slip_limbs(pxr.len);
             if (wave == 0) {
                 const int lp_ = slip_abs(pxr.len);
                 dig_t *dst = (dig_t *)(P.Llimbs + poff);
-                int z; uint64_t lo64;
-                const int cand_direct = pdirect && (int)(f_inf[bt] & 3u) == 2 && e_pivrow == (int) f_row[bt];
-                if (cand_direct) {
-                    /* multiplied a moment ago: written through by the multiplying wave, low limb and zeros stashed */
-                    z = (int) c_ctz[bt]; lo64 = (uint64_t) c_lo0[bt] | ((uint64_t) c_lo1[bt] << 32);
-                } else {
-                    const dig_t *src = pdirect ? (const dig_t *) dst : P.xd + (int64_t) e_pivrow * P.xcap;
-                    z = slip_publish_digits(dst, src, pdirect, lp_);
-                    lo64 = pdirect ? slip_ld_u64((const uint64_t *) dst) : *(const uint64_t *) src;
-                    slip_vm_drain();
-                }
+                /* where the digits are: the LDS slot the multiplying wave left, the slab (a class-A row that was not staged:
+                 * its stores were drained above), or the row's private x */
+                const dig_t *src = stg >= 0 ? (const dig_t *)(stage + stg * slotw) : (pdirect ? (const dig_t *) dst : P.xd + (int64_t) e_pivrow * P.xcap);
+                const int z = slip_publish_digits(dst, src, stg < 0 && pdirect, lp_);
+                const uint64_t lo64 = (stg < 0 && pdirect) ? slip_ld_u64((const uint64_t *) dst) : *(const uint64_t *) src;
                 if (lane == 0) {
                     SlipPiv pr; pr.off = poff; pr.len = pxr.len; pr.bits = pxr.bits; pr.ctz = z; pr.invlen = 0;
                     pr.lo = lo64; pr.inv64 = 0; pr.pad = 0;
@@ -745,14 +795,20 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                     slip_st_i32(&P.pinv[e_pivrow], k); slip_st_i32(&P.pinv[intermed2], intermed);
                     slip_st_i64(&P.Up[k + 1], Unz_ + (int) nUc_all + 1); slip_st_i64(&P.Lp[k + 1], Lnz_ + nLc);
                     slip_st_i64(&P.Uo[k + 1], Unl_ + (int64_t)(U_l + plimbs)); slip_st_i64(&P.Lo[k + 1], Lnl_ + (int64_t) Lb_total);
-                    slip_vm_drain();
-                    slip_st_i32(&st->F, k + 1);
+                }
+                SLIP_TR(7);                                       /* 7: publish stores issued */
+                slip_vm_drain();                                  /* the digits (all lanes) and the records (lane 0) have left */
+                if (lane == 0) {
+                    slip_st_frontier(st, k + 1, e_pivrow);
 #ifdef SLIP_PROFILING
                     if (t_last_) prof_[18] += slip_clock() - t_last_;
                     {
                         int32_t *tr = P.dbg + 8 * (int64_t) k; const unsigned long long nowc = slip_clock();
                         tr[0] = t_last_ ? (int32_t)(nowc - t_last_) : -1; tr[1] = 1; tr[2] = ncA + ncB; tr[3] = nrows;
                         tr[4] = (int32_t) tr_sweep_; tr[5] = (int32_t)(nowc - tr_t2_); tr[7] = P.worker;
+                        tr[6] = (int32_t) slip_realtime(); P.dbg[8 * (int64_t) P.n + k] = (int32_t) t_wait_[2];
+                        for (int q_ = 0; q_ < 8; q_++) P.dbg[9 * (int64_t) P.n + 8 * (int64_t) k + q_] = trs_[q_];
+                        P.dbg[9 * (int64_t) P.n + 8 * (int64_t) k + 7] = (int32_t)(nowc - trp_) + trs_[7] * 0;     /* 7b: drain */
                     }
 #endif
                     /* from now on the pivot row lives in the slab like a class-A row */
@@ -874,7 +930,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                     if (m1) base1 = slip_atomic_add_i32((int32_t *) wcnt2, slip_popc64(m1));
                     if (m2) base2 = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(m2));
                 }
-                base1 = (int) slip_shfl_u32((uint32_t) base1, 0); base2 = (int) slip_shfl_u32((uint32_t) base2, 0);
+                base1 = (int) slip_bcast0_u32((uint32_t) base1); base2 = (int) slip_bcast0_u32((uint32_t) base2);
                 const uint64_t below = (1ull << lane) - 1ull;
                 if (cls == 1) {
                     const int at = base1 + slip_popc64(m1 & below);
@@ -1136,7 +1192,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             slip_st_i64(&P.Up[k + 1], Unz + nUe); slip_st_i64(&P.Lp[k + 1], Lnz + nL);
             slip_st_i64(&P.Uo[k + 1], Unl + (int64_t) totU); slip_st_i64(&P.Lo[k + 1], Lnl + (int64_t) totL);
             slip_vm_drain();
-            slip_st_i32(&st->F, k + 1);
+            slip_st_frontier(st, k + 1, pivrow);
 #ifdef SLIP_PROFILING
             /* slot 18: from the moment this worker learnt that column k-1 was committed to its own commit */
             if (t_last_) prof_[18] += slip_clock() - t_last_;
@@ -1144,6 +1200,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 int32_t *tr = P.dbg + 8 * (int64_t) k; const unsigned long long nowc = slip_clock();
                 tr[0] = t_last_ ? (int32_t)(nowc - t_last_) : -1; tr[1] = 0; tr[2] = 0; tr[3] = nrows;
                 tr[4] = (int32_t) tr_sweep_; tr[5] = (int32_t)(nowc - tr_t2_); tr[7] = P.worker;
+                        tr[6] = (int32_t) slip_realtime(); P.dbg[8 * (int64_t) P.n + k] = (int32_t) t_wait_[2];
             }
 #endif
         }
@@ -1300,7 +1357,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
     if (sv[SV_ERR]) return SLIPDEV_GROW_X;
 
     /* forward substitution = the sweep over ALL pivot positions (slip_forward_sub.c:61-158) */
-    unsigned long long tw_[2] = {0, 0}, tl_ = 0;
+    unsigned long long tw_[3] = {0, 0, 0}, tl_ = 0;
     slip_sweep<FAST, false>(P, st, n, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac, tw_, &tl_);
     slip_block_sync();
     if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
@@ -1336,7 +1393,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
                 const uint64_t qm = slip_ballot(queue);
                 int qbase = 0;
                 if (lane == 0 && qm) qbase = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(qm));
-                qbase = (int) slip_shfl_u32((uint32_t) qbase, 0);
+                qbase = (int) slip_bcast0_u32((uint32_t) qbase);
                 if (queue) work[qbase + slip_popc64(qm & ((1ull << lane) - 1ull))] = (uint32_t) r;
             }
             slip_block_sync();
@@ -1411,7 +1468,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
                     const uint64_t qm = slip_ballot(queue);          /* queue slots per wave */
                     int qbase = 0;
                     if (lane == 0 && qm) qbase = slip_atomic_add_i32((int32_t *) wcnt, slip_popc64(qm));
-                    qbase = (int) slip_shfl_u32((uint32_t) qbase, 0);
+                    qbase = (int) slip_bcast0_u32((uint32_t) qbase);
                     if (queue) {
                         const int at = qbase + slip_popc64(qm & ((1ull << lane) - 1ull));
                         work[2 * at] = (uint32_t)(m - m0); work[2 * at + 1] = (uint32_t) qi;

@@ -53,7 +53,11 @@ SLIP_DEV void slip_reg_op_test(int op, const uint32_t *A, int la, const uint32_t
         const int lane = slip_lane();
         const uint32_t v = A[lane];
         uint32_t r = 0;
-        if (op == 20) r = slip_dpp_shr1(v, 0xAAAAu);
+        if (op == 24) r = slip_wave_sum_u32(v);
+        else if (op == 25) r = slip_wave_max_u32(v);
+        else if (op == 26) r = slip_wave_min_u32(v);
+        else if (op == 27) r = slip_bcast0_u32(v);
+        else if (op == 20) r = slip_dpp_shr1(v, 0xAAAAu);
         else if (op == 21) r = slip_dpp_shl1(v, 0xBBBBu);
         else if (op == 22) r = slip_readlane(v, lb);
         else if (op == 23) r = slip_shfl_up_u32(v, 1);
@@ -88,7 +92,7 @@ SLIP_DEV void slip_worker_exit(const SlipParams &P, SlipState *st)
     slip_block_sync();
     if (slip_tid() == 0) {
         if (slip_agent_add_i32(&st->exited, 1) == P.nworkers - 1) {
-            const int F = slip_ld_i32(&st->F);
+            int pr_; const int F = slip_ld_frontier(st, &pr_);
             st->k_next = F;
             st->Lnz = slip_ld_i64(&P.Lp[F]); st->Lnl = slip_ld_i64(&P.Lo[F]);
             st->Unz = slip_ld_i64(&P.Up[F]); st->Unl = slip_ld_i64(&P.Uo[F]);
@@ -462,9 +466,9 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     A_(dev_alloc(&f->dAp, (int64_t) n + 1)); A_(dev_alloc(&f->dAi, onz)); A_(dev_alloc(&f->dAlen, onz));
     A_(dev_alloc(&f->dAoff, onz)); A_(dev_alloc(&f->dAlimbs, ol)); A_(dev_alloc(&f->dq, n));
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 8 * (int64_t) n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 20 * (int64_t) n));
     A_(make_ident(f));
-    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 8 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 20 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc && hipMemset(P->piv, 0, (size_t) n * sizeof(SlipPiv)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     /* initial sizes: S->lnz/unz only size the first allocation in the reference too */
     P->Lcap_nz = opt.lnz_hint > 0 ? opt.lnz_hint : 4 * onz + n;
@@ -701,11 +705,11 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     int rc = 0;
 #define A_(call) do { if (!rc) rc = (call); } while (0)
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 8 * (int64_t) n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 20 * (int64_t) n));
     A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Lo, (int64_t) n + 1)); A_(dev_alloc(&P->Li, lnz)); A_(dev_alloc(&P->Le, lnz)); A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
     A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Uo, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, unz)); A_(dev_alloc(&P->Ue, unz)); A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
     A_(dev_alloc(&f->ds, 1));
-    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 8 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 20 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc) rc = alloc_x(f, 2 * maxdig + 8, 0);
 #undef A_
 #define UP_(dst, src, bytes) do { if (!rc && (bytes) > 0 && hipMemcpy((void *)(dst), (src), (size_t)(bytes), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR; } while (0)
@@ -900,6 +904,10 @@ extern "C" int slip_hip_factor_column_trace(const slip_hip_factor *f, int32_t *o
 {
     if (!f || !out || ncols <= 0 || ncols > f->n) return SLIP_HIP_INCORRECT_INPUT;
     CK(hipMemcpy(out, f->P.dbg, (size_t) ncols * 8 * 4, hipMemcpyDeviceToHost));
+    /* word 8: the 100 MHz chip clock when the column's worker saw its turn (kept behind the n trace records) */
+    CK(hipMemcpy(out + 8 * (int64_t) ncols, f->P.dbg + 8 * (int64_t) f->n, (size_t) ncols * 4, hipMemcpyDeviceToHost));
+    /* words 9..16: cycles of the sub-steps of the commit chain */
+    CK(hipMemcpy(out + 9 * (int64_t) ncols, f->P.dbg + 9 * (int64_t) f->n, (size_t) ncols * 8 * 4, hipMemcpyDeviceToHost));
     return SLIP_HIP_OK;
 }
 

@@ -44,6 +44,13 @@ static inline uint32_t slip_emu_shl1(const uint64_t *o, uint32_t fill) { int l =
 #define slip_dpp_shr1_in(v, in) slip_dpp_shr1((v), (in))
 #define slip_dpp_shr1_zero(v) slip_dpp_shr1((v), 0u)
 static inline void slip_valu_settle(void) {}
+/* value of lane 0 in every lane (all lanes active) */
+#define slip_bcast0_u32(v) ((uint32_t) emu::shfl((uint64_t)(v), 0, __LINE__))
+/* reductions over the 64 lanes, result in every lane (all lanes active) */
+static inline uint32_t slip_emu_red(const uint64_t *o, int op) { uint32_t r = (uint32_t) o[0]; for (int i = 1; i < 64; i++) { const uint32_t v = (uint32_t) o[i]; r = op == 0 ? r + v : (op == 1 ? (v > r ? v : r) : (v < r ? v : r)); } return r; }
+#define slip_wave_sum_u32(v) slip_emu_red(emu::collective((uint64_t)(uint32_t)(v), __LINE__), 0)
+#define slip_wave_max_u32(v) slip_emu_red(emu::collective((uint64_t)(uint32_t)(v), __LINE__), 1)
+#define slip_wave_min_u32(v) slip_emu_red(emu::collective((uint64_t)(uint32_t)(v), __LINE__), 2)
 /* (hi:acc) += a * b, a 96-bit per-lane accumulator */
 static inline void slip_mac96(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t b)
 {
@@ -67,6 +74,7 @@ static inline int32_t slip_agent_add_i32(int32_t *p, int32_t v) { int32_t o = *p
 static inline void slip_sleep(void) { emu::spin_yield(); }       /* a spin-wait iteration: let the other workgroups run */
 static inline void slip_sleep_short(void) { emu::spin_yield(); }
 static inline unsigned long long slip_clock(void) { return 0; }
+static inline unsigned long long slip_realtime(void) { return 0; }
 /* data other workgroups write / read during a launch (sc1 on the device; plain here: the emulator is sequentially consistent) */
 static inline uint32_t slip_ld_u32(const uint32_t *p) { return *(volatile const uint32_t *) p; }
 static inline int32_t  slip_ld_i32(const int32_t *p)  { return *(volatile const int32_t *) p; }
@@ -140,6 +148,32 @@ SLIP_DEV uint32_t slip_dpp_shr1_in(uint32_t v, uint32_t in)
     asm("v_writelane_b32 %0, %1, 0" : "+v"(sh) : "s"(in));
     return sh;
 }
+/* value of lane 0 in every lane (all lanes active): one v_readfirstlane instead of a trip through the LDS crossbar */
+SLIP_DEV uint32_t slip_bcast0_u32(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+/* reductions over the 64 lanes with DPP row shifts and row broadcasts (VALU only; ds_bpermute shuffles cost an LDS round
+ * trip per step); the total lands in lane 63 and is handed to every lane through an SGPR.  All lanes active. */
+#define SLIP_DPP_STEP(op, ctrl, rowmask, ident) { const uint32_t o_ = (uint32_t) __builtin_amdgcn_update_dpp((int)(ident), (int) v, ctrl, rowmask, 0xF, false); v = op(v, o_); }
+SLIP_DEV uint32_t slip_red_add_(uint32_t a, uint32_t b) { return a + b; }
+SLIP_DEV uint32_t slip_red_max_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+SLIP_DEV uint32_t slip_red_min_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+SLIP_DEV uint32_t slip_wave_sum_u32(uint32_t v)
+{
+    SLIP_DPP_STEP(slip_red_add_, 0x111, 0xF, 0u) SLIP_DPP_STEP(slip_red_add_, 0x112, 0xF, 0u) SLIP_DPP_STEP(slip_red_add_, 0x114, 0xF, 0u)
+    SLIP_DPP_STEP(slip_red_add_, 0x118, 0xF, 0u) SLIP_DPP_STEP(slip_red_add_, 0x142, 0xA, 0u) SLIP_DPP_STEP(slip_red_add_, 0x143, 0xC, 0u)
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
+SLIP_DEV uint32_t slip_wave_max_u32(uint32_t v)
+{
+    SLIP_DPP_STEP(slip_red_max_, 0x111, 0xF, 0u) SLIP_DPP_STEP(slip_red_max_, 0x112, 0xF, 0u) SLIP_DPP_STEP(slip_red_max_, 0x114, 0xF, 0u)
+    SLIP_DPP_STEP(slip_red_max_, 0x118, 0xF, 0u) SLIP_DPP_STEP(slip_red_max_, 0x142, 0xA, 0u) SLIP_DPP_STEP(slip_red_max_, 0x143, 0xC, 0u)
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
+SLIP_DEV uint32_t slip_wave_min_u32(uint32_t v)
+{
+    SLIP_DPP_STEP(slip_red_min_, 0x111, 0xF, 0xFFFFFFFFu) SLIP_DPP_STEP(slip_red_min_, 0x112, 0xF, 0xFFFFFFFFu) SLIP_DPP_STEP(slip_red_min_, 0x114, 0xF, 0xFFFFFFFFu)
+    SLIP_DPP_STEP(slip_red_min_, 0x118, 0xF, 0xFFFFFFFFu) SLIP_DPP_STEP(slip_red_min_, 0x142, 0xA, 0xFFFFFFFFu) SLIP_DPP_STEP(slip_red_min_, 0x143, 0xC, 0xFFFFFFFFu)
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
 /* results of the inline-asm VALU ops above may be read by a DPP op next: give the pipeline its two wait states */
 SLIP_DEV void slip_valu_settle(void) { asm volatile("s_nop 1"); }
 SLIP_DEV uint32_t slip_dpp_shr1_zero(uint32_t v) { return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x138, 0xF, 0xF, true); }
@@ -208,6 +242,7 @@ SLIP_DEV int64_t slip_agent_min_i64(int64_t *p, int64_t v) { return __hip_atomic
 SLIP_DEV unsigned long long slip_agent_add_u64(unsigned long long *p, unsigned long long v) { return __hip_atomic_fetch_add((slip_gu64 *) p, (uint64_t) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 SLIP_DEV unsigned long long slip_agent_max_u64(unsigned long long *p, unsigned long long v) { return __hip_atomic_fetch_max((slip_gu64 *) p, (uint64_t) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 SLIP_DEV unsigned long long slip_clock(void) { return (unsigned long long) clock64(); }
+SLIP_DEV unsigned long long slip_realtime(void) { return (unsigned long long) __builtin_amdgcn_s_memrealtime(); }   /* 100 MHz, chip-wide */
 SLIP_DEV int slip_clz32(uint32_t v) { return __clz((int) v); }
 SLIP_DEV int slip_ctz32(uint32_t v) { return v ? __ffs((int) v) - 1 : 32; }
 SLIP_DEV int slip_clz64(uint64_t v) { return __clzll((long long) v); }

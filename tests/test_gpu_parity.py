@@ -157,6 +157,22 @@ def test_gpu_wave_limb_ops(op):
         assert np.array_equal(out, np.array(exp, dtype=np.uint32)), (op, la, lb, W)
 
 
+def test_gpu_wave_reductions():
+    """the DPP wave reductions / lane-0 broadcast of wave_shim.h (used on the commit chain) vs numpy"""
+    from slip_lu_amd import _lib
+    lib = _lib.load()
+    rnd = np.random.RandomState(3)
+    nops = 16
+    a = rnd.randint(0, 2 ** 24, size=nops * 64).astype(np.uint32)
+    a[64:128] = 0; a[128:192] = 0xFFFFFFFF >> 8; a[192] = 7
+    b = np.zeros(nops, np.uint32)
+    for op, fn in ((24, lambda v: np.uint32(v.sum() & 0xFFFFFFFF)), (25, lambda v: v.max()), (26, lambda v: v.min()), (27, lambda v: v[0])):
+        out = np.zeros(nops * 64, np.uint32)
+        assert lib.slip_hip_wave_op_test(op, nops, 64, 1, 64, a.ctypes.data, b.ctypes.data, out.ctypes.data) == 0
+        for t in range(nops):
+            assert (out[64 * t:64 * t + 64] == fn(a[64 * t:64 * t + 64])).all(), (op, t)
+
+
 def test_gpu_subtree_farm_law():
     """independent diagonal blocks factorised one by one on the HIP path and reassembled with
     slip_lu_amd.parallel (pivot chains -> scales) equal the HIP factorisation of the whole matrix."""

@@ -30,10 +30,19 @@ for name in sys.argv[1].split(","):
         print(f"    {label:36s} {out[slot] / K:12.2f}")
     if hasattr(f.lib, "slip_hip_factor_column_trace"):
         import numpy as np
-        tr = np.zeros(8 * i["K"], np.int32)
+        tr = np.zeros(17 * i["K"], np.int32)
         f.lib.slip_hip_factor_column_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         if f.lib.slip_hip_factor_column_trace(f.h, tr.ctypes.data, i["K"]) == 0:
-            tr = tr.reshape(-1, 8)
+            seen = tr[8 * i["K"]:9 * i["K"]].astype(np.int64)
+            sub = tr[9 * i["K"]:].reshape(-1, 8)
+            names = ["sweep tail", "loads+classify", "rho staging+barrier", "reduce+barrier", "marking+barrier", "cand multiply+barrier", "search", "publish issue (7b: then drain)"]
+            good = sub[:, 1] > 0
+            print("    chain sub-steps, median cycles: " + ", ".join(f"{n} {int(np.median(sub[good, q]))}" for q, n in enumerate(names)))
+            tr = tr[:8 * i["K"]].reshape(-1, 8)
+            hop = (seen[1:] - tr[:-1, 6].astype(np.int64)) & 0xFFFFFFFF
+            hop = hop[(seen[1:] != 0) & (hop < 10 ** 7)] * 10.0        # ns
+            if len(hop):
+                print(f"    hand-off (F stored by column k-1 -> seen by column k's worker): mean {hop.mean():.0f} ns median {np.median(hop):.0f} ns p90 {np.percentile(hop, 90):.0f} ns")
             c = tr[:, 0].astype(np.float64)
             ok = c >= 0
             print(f"    commit-chain cycles per column: n={ok.sum()} mean {c[ok].mean():.0f} median {np.median(c[ok]):.0f} "
