@@ -272,7 +272,7 @@ static int32_t default_workers(const slip_hip_factor *f, int32_t xcap)
 #endif
     const int64_t lds_bytes = (int64_t) f->lds_words * 4;
     int per_cu = (int)((160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1));
-    const int by_waves = 16 / (f->waves > 0 ? f->waves : 1);          /* two waves per SIMD */
+    const int by_waves = 8 / (f->waves > 0 ? f->waves : 1);           /* 232 VGPRs: two waves per SIMD, eight per CU */
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     int64_t w = (int64_t) cus * per_cu;
@@ -366,7 +366,7 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
 /* options -> the handle's launch shape */
 static void apply_options(slip_hip_factor *f, const slip_hip_options &opt)
 {
-    f->waves = opt.waves > 0 ? opt.waves : 4;
+    f->waves = opt.waves > 0 ? opt.waves : 8;
     if (f->waves > SLIP_MAX_WAVES) f->waves = SLIP_MAX_WAVES;
     f->nworkers = opt.workers > 0 ? opt.workers : 0;      /* 0: chosen in alloc_x once the LDS need is known */
     if (f->nworkers > 4096) f->nworkers = 4096;

@@ -2,7 +2,7 @@
 # Round-end measurement on the GPU box (run through gpurun): full bench line, rocprofv3 kernel statistics of the
 # headline-only bench, two separate PMC passes (FETCH_SIZE, WRITE_SIZE), reduced to gpurun_out/final/profiles/<tag>_*.
 set -o pipefail
-TAG=${1:-v5}
+TAG=${1:-v1}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final
 mkdir -p "$O" && cd /tmp && export TMPDIR=/tmp
