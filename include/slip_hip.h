@@ -132,6 +132,14 @@ int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
 /* device time of the solve kernels of the last slip_hip_factor_solve, milliseconds */
 double slip_hip_factor_solve_ms(const slip_hip_factor *f);
 
+/* Subtree farm (no counterpart in the reference, which has no parallelism): multiply the K committed
+ * columns by per-column scales on the device -- L(:,k) and rho[k] by scale[k], an entry of U in the row whose pivot sits
+ * at position p by scale[p] -- where scale[k] is the product of the pivots the OTHER independent blocks had produced when
+ * global column k was eliminated (slip_lu_amd/parallel.py: subtree_scales).  scale[k]: signed limb counts slen[K], limbs back
+ * to back.  The rescaled copy is what slip_hip_factor_download / _info then serve, until the next reset (or rescale);
+ * the handle's own factors are untouched, so run / solve keep working on the local values. */
+int slip_hip_factor_rescale(slip_hip_factor *f, const int32_t *slen, const uint64_t *slimbs, void *stream);
+
 void slip_hip_factor_destroy(slip_hip_factor *f);
 
 /* Deterministic synthetic CSC generator of the benchmark configs

@@ -49,7 +49,7 @@ class Factorization:
     """A resident REF LU factorisation on one GPU (handle of slip_hip_factor_*)."""
 
     def __init__(self, n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, limb_cap=0, waves=0,
-                 lnz_hint=0, unz_hint=0, workers=0, lib_path=None):
+                 lnz_hint=0, unz_hint=0, workers=0, lib_path=None, debug_flags=0):
         self.lib = _lib.load(lib_path)
         self.n = int(n)
         Ap = np.ascontiguousarray(Ap, dtype=np.int64)
@@ -59,7 +59,7 @@ class Factorization:
         if Alimbs.size == 0:
             Alimbs = np.zeros(1, dtype=np.uint64)
         q = np.ascontiguousarray(q, dtype=np.int32)
-        opt = _lib.Options(pivot, tol, limb_cap, waves, lnz_hint, unz_hint, workers, 0)
+        opt = _lib.Options(pivot, tol, limb_cap, waves, lnz_hint, unz_hint, workers, debug_flags)
         self.h = C.c_void_p()
         rc = self.lib.slip_hip_factor_create(C.byref(self.h), self.n, Ap.ctypes.data, Ai.ctypes.data,
                                              Alen.ctypes.data, Alimbs.ctypes.data, q.ctypes.data,
@@ -150,6 +150,33 @@ class Factorization:
         self.lib.slip_hip_free(px)
         return xlen, xlimbs
 
+    def pivots(self):
+        """the pivot chain rho[0..K) only (signed limb counts, limbs): what the subtree farm exchanges"""
+        i = self.info()
+        K = i["K"]
+        rholen = np.zeros(max(K, 1), np.int32)
+        rho = np.zeros(max(i["l_limbs"], 1), np.uint64)
+        cap = C.c_int64(rho.size)
+        rc = self.lib.slip_hip_factor_download(self.h, None, None, None, None, None, None, None, None,
+                                               rholen.ctypes.data, rho.ctypes.data, C.byref(cap), None)
+        if rc:
+            raise SlipError(rc, "slip_hip_factor_download")
+        return rholen[:K], rho[:cap.value].copy()
+
+    def rescale(self, scales, stream=None):
+        """Subtree farm: multiply the committed columns by per-column big-integer scales on the device
+        (slip_hip_factor_rescale): L(:,k), rho[k] by scales[k]; U entries by the scale of their row's pivot position."""
+        lens, limbs = [], []
+        for v in scales:
+            a, l = abs(int(v)), 0
+            while a:
+                limbs.append(a & (2 ** 64 - 1)); a >>= 64; l += 1
+            lens.append(-l if v < 0 else l)
+        lens = np.array(lens, np.int32); limbs = np.array(limbs if limbs else [0], np.uint64)
+        rc = self.lib.slip_hip_factor_rescale(self.h, lens.ctypes.data, limbs.ctypes.data, C.c_void_p(stream or 0))
+        if rc:
+            raise SlipError(rc, "slip_hip_factor_rescale")
+
     def solve_ms(self):
         return self.lib.slip_hip_factor_solve_ms(self.h)
 
@@ -166,10 +193,10 @@ class Factorization:
 
 
 def factorize(n, Ap, Ai, Alen, Alimbs, q, pivot=3, tol=1.0, kmax=0, limb_cap=0, waves=0, check=True,
-              lib_path=None, workers=0, lnz_hint=0, unz_hint=0):
+              lib_path=None, workers=0, lnz_hint=0, unz_hint=0, debug_flags=0):
     """One-shot SLIP_LU_factorize on the GPU; returns the canonical factor dict."""
     f = Factorization(n, Ap, Ai, Alen, Alimbs, q, pivot=pivot, tol=tol, limb_cap=limb_cap, waves=waves,
-                      lib_path=lib_path, workers=workers, lnz_hint=lnz_hint, unz_hint=unz_hint)
+                      lib_path=lib_path, workers=workers, lnz_hint=lnz_hint, unz_hint=unz_hint, debug_flags=debug_flags)
     try:
         rc = f.run(kmax, check=check)
         out = f.download()

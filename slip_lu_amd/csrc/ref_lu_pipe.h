@@ -107,6 +107,7 @@ typedef struct SlipParams {
     int32_t k0, t0;                                 /* ticket t0 + d is column k0 + d in this launch                    */
     int32_t bitmap_in_lds, scratch_in_lds;          /* where the bitmap / wave scratch live (generic kernel)            */
     int32_t nworkers, worker;
+    int32_t no_early, pad_e;                        /* diagnostics: 1 = every column takes the complete path (no early commit) */
     int64_t priv_rows;                              /* rows per worker of the private arrays (= n)                      */
     int32_t *dbg;
 } SlipParams;
@@ -153,7 +154,8 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
        SV_LNZ = 8 /* int64 slots from here */, SV_LNL = 10, SV_UNZ = 12, SV_UNL = 14,
        SV_LALLOC = 16 /* limbs of the L slab handed out to this column's direct rows */, SV_LEXACT = 18,
        SV_NROWS = 24 /* rows discovered so far (length of rlist) */, SV_K = 25, SV_TAG = 26, SV_ABORT = 27,
-       SV_TMP2 = 28, SV_F2 = 29 /* ready frontier as this worker knows it */, SV_TMP3 = 30, SV_ACNT = 31 /* class-A rows of the early commit (zeroed at column start) */ };
+       SV_TMP2 = 28, SV_F2 = 29 /* ready frontier as this worker knows it */, SV_TMP3 = 30, SV_ACNT = 31 /* class-A rows of the early commit (zeroed at column start) */,
+       SV_EPR = 32, SV_EPP = 33, SV_EST = 34 /* early commit: pivot row, its position, status (written by wave 0) */ };
 
 SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
 SLIP_DEV int slip_abs(int32_t v) { return v < 0 ? -v : v; }
@@ -836,7 +838,11 @@ template <int D> SLIP_DEV void slip_mul_row_finish(const SlipParams &P, const Sl
     /* bulk L data: plain (coalesced) stores; the worker's release fence before Lready[k] publishes them (a 4-byte
      * write-through store is one fabric write per lane: 6x the time of these rows).  A candidate of the early commit may
      * become the pivot: its digits are also left in an LDS slot, from where the publishing wave writes them through. */
+#ifdef SLIP_BULK_SC1
+    wr_store_s<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
+#else
     wr_store_g<D>((dig_t *)(P.Llimbs + off), Y, (len + 1) & ~1);
+#endif
     const uint32_t d1 = len ? wr_digit<D>(Y, len - 1) : 0u;
     const int neg = (int)((rec3 >> 2) & 1u) ^ (M.len < 0);
     const int32_t slen = neg ? -len : len;

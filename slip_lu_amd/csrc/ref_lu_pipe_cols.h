@@ -446,7 +446,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     uint32_t *f_k0 = lds + SLIP_LDS_KEYS, *f_k1 = f_k0 + SLIP_PAT_CAP;                    /* search keys of exact candidates */
     const int scheme = P.pivot_scheme;
     const int kind = (scheme == 2) ? 2 : ((scheme == 4 || scheme == 5) ? 1 : 0);   /* 0 smallest, 1 largest, 2 first nonzero */
-    const bool try_early = k >= 1 && nrows <= SLIP_FAST_CAP;
+    const bool try_early = k >= 1 && nrows <= SLIP_FAST_CAP && !P.no_early;
     /* the first round of loads of the commit chain: everything is issued before anything is waited for -- this thread's
      * row (its position and state), then rho[k-1]'s record, and the column cursors by six lanes of the last wave */
     int r0_ = 0, pos0_ = 0; SlipRow xr0_; xr0_.len = 0; xr0_.h = 0; xr0_.bits = 0; xr0_.tag = 0;
@@ -720,6 +720,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 }
                 return key;
             };
+            /* ONE wave searches and publishes (the publishing wave rewrites the pivot row's state: nobody else may be
+             * looking at it); the others wait at the barrier below and read the outcome there */
+            if (wave == 0) {
+            int est = 0;
             uint64_t mk = ~0ull;
             for (int c0 = 0; c0 < ncand; c0 += SLIP_WAVE) {
                 const int c = c0 + lane;
@@ -747,17 +751,19 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                     if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && f_pos[tt] < f_pos[bt])) bt = tt;
                 }
             }
-            if (bt < 0) return SLIPDEV_INTERNAL;
+            if (bt < 0) { est = SLIPDEV_INTERNAL; bt = 0; }
             e_pivrow = (int) f_row[bt]; e_pivpos = (int) f_pos[bt];
             int stg = (int)((f_inf[bt] >> 26) & 31u) - 1;     /* LDS slot of the pivot's digits, or -1 */
             /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); col's value is exact: it was a candidate */
-            if (diag_cand && e_pivrow != col) {
+            if (!est && diag_cand && e_pivrow != col) {
                 int derr = 0;
                 const int take = diag_rule(e_pivrow, &derr);
-                if (derr) return SLIPDEV_GROW_X;
-                if (take) { e_pivrow = col; e_pivpos = pc_col; stg = -1; }
+                if (derr) est = SLIPDEV_GROW_X;
+                else if (take) { e_pivrow = col; e_pivpos = pc_col; stg = -1; }
             }
             SLIP_STAMP(13);
+            if (est) { if (lane == 0) sv[SV_EST] = est; }
+            else {
             SLIP_TR(6);                                       /* 6: search + diag */
             /* stage 1, early: the pivot's digits written through to the L slab (its class-A slot, or the reserved slot behind
              * those), the pivot record, the permutation swap, the column pointers (limb offsets from the bounds), ONE
@@ -777,7 +783,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 poff = pdirect ? *(const int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) : Lnl_ + (int64_t) nA * slot;
             }
             const uint64_t plimbs = (uint64_t) slip_limbs(pxr.len);
-            if (wave == 0) {
+            {
                 const int lp_ = slip_abs(pxr.len);
                 dig_t *dst = (dig_t *)(P.Llimbs + poff);
                 /* where the digits are: the LDS slot the multiplying wave left, the slab (a class-A row that was not staged:
@@ -817,10 +823,15 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                         *(int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) = poff;
                     }
                     sv64[SV_LALLOC / 2] = (int64_t)((uint64_t) nA * (uint64_t) slot + (pdirect ? 0ull : plimbs));
+                    sv[SV_EPR] = e_pivrow; sv[SV_EPP] = e_pivpos; sv[SV_EST] = 0;
                 }
             }
-            early = 1;
+            }       /* !est */
+            }       /* wave 0 */
             slip_block_sync();
+            if (sv[SV_EST]) return sv[SV_EST];
+            e_pivrow = sv[SV_EPR]; e_pivpos = sv[SV_EPP];
+            early = 1;
             SLIP_STAMP(6);
 #ifdef SLIP_PROFILING
             if (tid == 0) { prof_[23] += 1; prof_[15] += (unsigned long long)(ncA + ncB); }   /* early commits; their candidates that needed arithmetic */
@@ -1149,7 +1160,11 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             } else {
                 const int64_t at = Lnz + (e - nUe);
                 const int64_t off = direct ? doff : Lnl + (int64_t)(lalloc + baseL + el);
+#ifdef SLIP_BULK_SC1
+                if (at < P.Lcap_nz) { slip_st_i32(&P.Li[at], r); SlipEnt en; en.len = xl; en.bits = xb; en.off = off; slip_st_ent(&P.Le[at], en); }
+#else
                 if (at < P.Lcap_nz) { P.Li[at] = r; SlipEnt en; en.len = xl; en.bits = xb; en.off = off; P.Le[at] = en; }   /* plain: published by the release before Lready[k] */
+#endif
                 if (use_tab && !direct) tab[3 * SLIP_TAB_CAP + pt] = (uint32_t)(off - Lnl);     /* copy destination, flag bit clear */
             }
         }
@@ -1252,7 +1267,11 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         }
         const int lw = (slip_abs(xl) + 1) & ~1;
         if (isU) { for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = src_shared ? slip_ld_u32(srcx + c) : srcx[c]; }
+#ifdef SLIP_BULK_SC1
+        else     { for (int c = lane; c < lw; c += SLIP_WAVE) slip_st_u32(dst + c, srcx[c]); }
+#else
         else     { for (int c = lane; c < lw; c += SLIP_WAVE) dst[c] = srcx[c]; }
+#endif
     }
     }
     slip_vm_drain();

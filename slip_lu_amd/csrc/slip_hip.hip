@@ -100,6 +100,75 @@ SLIP_DEV void slip_worker_exit(const SlipParams &P, SlipState *st)
     }
 }
 
+/* Subtree farm: rescale a block's factors by the pivots the OTHER blocks produced meanwhile.
+ * One wavefront per stored entry: out = entry * scale[s], s = the entry's column (L) or the pivot position of its
+ * row (U).  Entries are written into new slabs at offsets the host laid out from the operands' lengths. */
+struct SlipRescaleArgs {
+    const SlipEnt *ent; const uint64_t *limbs; const int32_t *idx; int64_t nz;     /* source entries; idx: row ids */
+    const int64_t *colp; int32_t ncols;                                            /* L: column pointers (scale = column); U: null */
+    const int32_t *pinv;                                                           /* U: scale = pinv[row]                          */
+    const int32_t *slen; const int64_t *soff; const uint64_t *slimbs;              /* scales: signed digit counts, limb offsets      */
+    SlipEnt *oent; uint64_t *olimbs;                                               /* destination (oent[e].off set by the host)     */
+    int64_t *pividx; const int32_t *row_perm;                                      /* L: which entry of column k is the pivot         */
+};
+
+template <int D> SLIP_DEV void slip_rescale_entry_reg(const dig_t *a, int la, const dig_t *b, int lb, dig_t *out, int W, int *len_out, uint32_t *top_out)
+{
+    WR<D> A = wr_load<D>(a, la), B = wr_load<D>(b, lb);
+    WR<D> Y = la <= lb ? wr_mul<D>(A, la, B) : wr_mul<D>(B, lb, A);
+    const int len = wr_len<D>(Y);
+    wr_store<D>(out, Y, (len + 1) & ~1);
+    (void) W;
+    *len_out = len; *top_out = len ? wr_digit<D>(Y, len - 1) : 0u;
+}
+
+#ifndef SLIP_EMULATE
+__global__ void __launch_bounds__(256)
+slip_rescale_kernel(SlipRescaleArgs A)
+#else
+static void slip_rescale_body(SlipRescaleArgs A)
+#endif
+{
+    const int lane = slip_lane();
+    const int64_t wave0 = (int64_t) slip_block() * slip_nwaves() + slip_wave(), nwaves = (int64_t) slip_nblocks() * slip_nwaves();
+    for (int64_t e = wave0; e < A.nz; e += nwaves) {
+        const SlipEnt en = A.ent[e];
+        const int row = A.idx[e];
+        int sidx;
+        if (A.colp) {                       /* column of entry e: binary search over the column pointers */
+            int lo = 0, hi = A.ncols - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.colp[mid] <= e) lo = mid; else hi = mid - 1; }
+            sidx = lo;
+        } else sidx = A.pinv[row];
+        const int32_t sl = A.slen[sidx];
+        const dig_t *a = (const dig_t *)(A.limbs + en.off), *b = (const dig_t *)(A.slimbs + A.soff[sidx]);
+        const int la = slip_abs(en.len), lb = slip_abs(sl);
+        SlipEnt o = A.oent[e];
+        dig_t *out = (dig_t *)(A.olimbs + o.off);
+        int len = 0; uint32_t top = 0;
+        if (la == 0) { len = 0; }
+        else {
+            const int W = la + lb;
+            if (W <= 64) slip_rescale_entry_reg<1>(a, la, b, lb, out, W, &len, &top);
+            else if (W <= 128) slip_rescale_entry_reg<2>(a, la, b, lb, out, W, &len, &top);
+            else if (W <= 192) slip_rescale_entry_reg<3>(a, la, b, lb, out, W, &len, &top);
+            else if (W <= 256) slip_rescale_entry_reg<4>(a, la, b, lb, out, W, &len, &top);
+            else {
+                const int Wp = (W + 1) & ~1;
+                wb_mul_lo(out, a, la, b, lb, Wp);
+                len = wb_len(out, Wp);
+                top = len ? out[len - 1] : 0u;
+            }
+        }
+        if (lane == 0) {
+            o.len = (slip_sgn(en.len) * slip_sgn(sl)) < 0 ? -len : len;
+            o.bits = len ? 32 * len - slip_clz32(top) : 0;
+            A.oent[e] = o;
+            if (A.colp && A.row_perm[sidx] == row) A.pividx[sidx] = e;
+        }
+    }
+}
+
 #ifndef SLIP_EMULATE
 #define SLIP_MAX_WAVES 8                   /* at most 512 threads per worker: 256 VGPRs per lane, two waves per SIMD */
 template <bool FAST>
@@ -191,6 +260,8 @@ struct slip_hip_factor {
     double kernel_ms, solve_ms;
     hipEvent_t ev0, ev1;
     int32_t *ident;        /* device: 0..n-1 (reset copies it into pinv / row_perm) */
+    /* subtree farm: the rescaled copy of the committed factors (slip_hip_factor_rescale); download serves it while it exists */
+    SlipEnt *rsLe, *rsUe; uint64_t *rsLl, *rsUl; int64_t rsLnl, rsUnl, rsLexact, rsUexact; int64_t *rspiv; int32_t rescaled;
     /* owned device arrays that are only reachable through const pointers in P */
     int64_t *dAp; int32_t *dAi, *dAlen; int64_t *dAoff; uint64_t *dAlimbs; int32_t *dq;
 };
@@ -198,6 +269,8 @@ struct slip_hip_factor {
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
         fprintf(stderr, "slip_hip: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
         return SLIP_HIP_DEVICE_ERROR; } } while (0)
+
+static void rescale_drop(slip_hip_factor *f);
 
 template <class T> static int dev_alloc(T **p, int64_t count)
 {
@@ -330,6 +403,7 @@ extern "C" int slip_hip_factor_reset(slip_hip_factor *f)
     if (!f || f->factors_only) return SLIP_HIP_INCORRECT_INPUT;
     SlipParams *P = &f->P;
     const int32_t n = f->n;
+    if (f->rescaled) rescale_drop(f);
     CK(hipMemcpyAsync(P->pinv, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
     CK(hipMemcpyAsync(P->row_perm, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
     CK(hipMemsetAsync(P->Lready, 0, (size_t) n * 4, 0));
@@ -358,6 +432,7 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
     hipFree(P->Up); hipFree(P->Uo); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
     hipFree(P->Lready); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg);
     hipFree(f->ds); hipFree(f->ident);
+    rescale_drop(f);
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
     free(f);
@@ -369,6 +444,7 @@ static void apply_options(slip_hip_factor *f, const slip_hip_options &opt)
     f->waves = opt.waves > 0 ? opt.waves : 8;
     if (f->waves > SLIP_MAX_WAVES) f->waves = SLIP_MAX_WAVES;
     f->nworkers = opt.workers > 0 ? opt.workers : 0;      /* 0: chosen in alloc_x once the LDS need is known */
+    f->P.no_early = opt.reserved & 1;
     if (f->nworkers > 4096) f->nworkers = 4096;
 }
 
@@ -890,6 +966,122 @@ extern "C" int slip_hip_factor_solve(slip_hip_factor *f, int32_t nrhs, const int
 
 extern "C" double slip_hip_factor_solve_ms(const slip_hip_factor *f) { return f ? f->solve_ms : 0.0; }
 
+/* ---- subtree farm: multiply the committed factors by per-column scales ---- */
+static void rescale_drop(slip_hip_factor *f)
+{
+    hipFree(f->rsLe); hipFree(f->rsUe); hipFree(f->rsLl); hipFree(f->rsUl); hipFree(f->rspiv);
+    f->rsLe = f->rsUe = NULL; f->rsLl = f->rsUl = NULL; f->rspiv = NULL; f->rescaled = 0;
+}
+
+static int rescale_one(slip_hip_factor *f, int isL, int64_t nz, int64_t nl_alloc, const int32_t *sdig, const int32_t *dslen, const int64_t *dsoff,
+                       const uint64_t *dslimbs, hipStream_t stream)
+{
+    SlipParams *P = &f->P;
+    const int32_t K = f->hs.F;
+    if (nz <= 0) return 0;
+    SlipEnt *he = (SlipEnt *) malloc((size_t) nz * sizeof(SlipEnt));
+    int32_t *hidx = (int32_t *) malloc((size_t) nz * 4), *hpinv = (int32_t *) malloc((size_t) f->n * 4);
+    int64_t *hp = (int64_t *) malloc(((size_t) K + 1) * 8);
+    if (!he || !hidx || !hpinv || !hp) { free(he); free(hidx); free(hpinv); free(hp); return SLIP_HIP_OUT_OF_MEMORY; }
+    int rc = 0;
+    if (hipMemcpy(he, isL ? P->Le : P->Ue, (size_t) nz * sizeof(SlipEnt), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(hidx, isL ? P->Li : P->Ui, (size_t) nz * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(hpinv, P->pinv, (size_t) f->n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(hp, isL ? P->Lp : P->Up, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    /* lay the products out: digits(entry) + digits(scale) bound the product */
+    int64_t o = 0;
+    if (!rc) {
+        int32_t c = 0;
+        for (int64_t e = 0; e < nz; e++) {
+            while (c + 1 <= K && hp[c + 1] <= e) c++;
+            const int32_t sidx = isL ? c : hpinv[hidx[e]];
+            if (sidx < 0 || sidx >= K) { rc = SLIP_HIP_INCORRECT_INPUT; break; }
+            const int32_t la = he[e].len < 0 ? -he[e].len : he[e].len, lb = sdig[sidx];
+            he[e].off = o;
+            o += la ? (la + lb + 2) / 2 : 0;
+        }
+    }
+    SlipEnt *de = NULL; uint64_t *dl = NULL;
+    if (!rc) rc = dev_alloc(&de, nz);
+    if (!rc) rc = dev_alloc(&dl, o > 0 ? o : 1);
+    if (!rc && hipMemcpy(de, he, (size_t) nz * sizeof(SlipEnt), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc) {
+        SlipRescaleArgs A; memset(&A, 0, sizeof A);
+        A.ent = isL ? P->Le : P->Ue; A.limbs = isL ? P->Llimbs : P->Ulimbs; A.idx = isL ? P->Li : P->Ui; A.nz = nz;
+        A.colp = isL ? P->Lp : NULL; A.ncols = K; A.pinv = P->pinv;
+        A.slen = dslen; A.soff = dsoff; A.slimbs = dslimbs; A.oent = de; A.olimbs = dl; A.pividx = f->rspiv; A.row_perm = P->row_perm;
+#ifndef SLIP_EMULATE
+        int64_t blocks = (nz + 3) / 4; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(slip_rescale_kernel, dim3((unsigned) blocks), dim3(256), 0, stream, A);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+#else
+        emu::launch(2, 128, [A]() { slip_rescale_body(A); }, 256 * 1024, 1);
+#endif
+    }
+    if (!rc) {
+        if (isL) { f->rsLe = de; f->rsLl = dl; f->rsLnl = o; }
+        else     { f->rsUe = de; f->rsUl = dl; f->rsUnl = o; }
+        de = NULL; dl = NULL;
+    }
+    if (de) hipFree(de);
+    if (dl) hipFree(dl);
+    (void) nl_alloc;
+    free(he); free(hidx); free(hpinv); free(hp);
+    return rc;
+}
+
+extern "C" int slip_hip_factor_rescale(slip_hip_factor *f, const int32_t *slen, const uint64_t *slimbs, void *stream_v)
+{
+    if (!f || !slen || !slimbs) return SLIP_HIP_INCORRECT_INPUT;
+    hipStream_t stream = (hipStream_t) stream_v;
+    const int32_t K = f->hs.F;
+    if (K <= 0) return SLIP_HIP_INCORRECT_INPUT;
+    /* scales: signed limb counts -> signed digit counts + limb offsets */
+    int32_t *hd = (int32_t *) malloc((size_t) K * 4), *habs = (int32_t *) malloc((size_t) K * 4);
+    int64_t *ho = (int64_t *) malloc((size_t) K * 8);
+    if (!hd || !habs || !ho) { free(hd); free(habs); free(ho); return SLIP_HIP_OUT_OF_MEMORY; }
+    int64_t o = 0;
+    for (int32_t k = 0; k < K; k++) {
+        int64_t l = slen[k] < 0 ? -(int64_t) slen[k] : slen[k];
+        if (l == 0) { free(hd); free(habs); free(ho); return SLIP_HIP_INCORRECT_INPUT; }     /* a scale is a product of pivots: never zero */
+        ho[k] = o;
+        const uint64_t *src = slimbs + o;
+        o += l;
+        while (l > 0 && src[l - 1] == 0) l--;
+        int32_t dig = (int32_t)(2 * l);
+        if (l > 0 && (src[l - 1] >> 32) == 0) dig--;
+        habs[k] = dig; hd[k] = slen[k] < 0 ? -dig : dig;
+    }
+    int32_t *dslen = NULL; int64_t *dsoff = NULL; uint64_t *dsl = NULL;
+    int rc = 0;
+    if (dev_alloc(&dslen, K) || dev_alloc(&dsoff, K) || dev_alloc(&dsl, o)) rc = SLIP_HIP_OUT_OF_MEMORY;
+    if (!rc && (hipMemcpy(dslen, hd, (size_t) K * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dsoff, ho, (size_t) K * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dsl, slimbs, (size_t) o * 8, hipMemcpyHostToDevice) != hipSuccess)) rc = SLIP_HIP_DEVICE_ERROR;
+    rescale_drop(f);
+    if (!rc) rc = dev_alloc(&f->rspiv, K);
+    if (!rc) rc = rescale_one(f, 1, f->hs.Lnz, f->hs.Lnl, habs, dslen, dsoff, dsl, stream);
+    if (!rc) rc = rescale_one(f, 0, f->hs.Unz, f->hs.Unl, habs, dslen, dsoff, dsl, stream);
+    if (!rc) {
+        /* exact limb totals of the rescaled factors (download sizes its arrays from them) */
+        SlipEnt *he = (SlipEnt *) malloc((size_t)(f->hs.Lnz > f->hs.Unz ? f->hs.Lnz : f->hs.Unz) * sizeof(SlipEnt));
+        if (!he) rc = SLIP_HIP_OUT_OF_MEMORY;
+        for (int pass = 0; pass < 2 && !rc; pass++) {
+            const int64_t nz = pass == 0 ? f->hs.Lnz : f->hs.Unz;
+            if (hipMemcpy(he, pass == 0 ? f->rsLe : f->rsUe, (size_t) nz * sizeof(SlipEnt), hipMemcpyDeviceToHost) != hipSuccess) { rc = SLIP_HIP_DEVICE_ERROR; break; }
+            int64_t tot = 0;
+            for (int64_t e = 0; e < nz; e++) { const int32_t d = he[e].len < 0 ? -he[e].len : he[e].len; tot += (d + 1) >> 1; }
+            if (pass == 0) f->rsLexact = tot; else f->rsUexact = tot;
+        }
+        free(he);
+        if (!rc) f->rescaled = 1;
+    }
+    if (rc) rescale_drop(f);
+    hipFree(dslen); hipFree(dsoff); hipFree(dsl);
+    free(hd); free(habs); free(ho);
+    return rc;
+}
+
 /* diagnostic: per-phase shader cycles of the last run (zeros unless built with -DSLIP_PROFILE_PHASES) */
 extern "C" int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned long long *out24)
 {
@@ -916,7 +1108,7 @@ extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)
     if (!f || !o) return SLIP_HIP_INCORRECT_INPUT;
     const SlipState *h = &f->hs;
     o->n = f->n; o->K = h->F; o->status = f->last_status; o->window_end = f->window_end;
-    o->lnz = h->Lnz; o->unz = h->Unz; o->l_limbs = h->Lnl_exact; o->u_limbs = h->Unl_exact;
+    o->lnz = h->Lnz; o->unz = h->Unz; o->l_limbs = f->rescaled ? f->rsLexact : h->Lnl_exact; o->u_limbs = f->rescaled ? f->rsUexact : h->Unl_exact;
     o->n_upd = (int64_t) h->c_upd; o->b_read = (int64_t) h->c_read; o->b_write = (int64_t) h->c_write;
     o->n_src = (int64_t) h->c_src; o->l_streamed = (int64_t) h->c_streamed;
     o->max_limbs = (int64_t)((h->c_maxdig + 1) / 2);
@@ -974,14 +1166,28 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
     if (Up) CK(hipMemcpy(Up, P->Up, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost));
     if (Li && h->Lnz) CK(hipMemcpy(Li, P->Li, (size_t) h->Lnz * 4, hipMemcpyDeviceToHost));
     if (Ui && h->Unz) CK(hipMemcpy(Ui, P->Ui, (size_t) h->Unz * 4, hipMemcpyDeviceToHost));
-    if ((Llen || Llimbs) && (e = fetch_factor(Llen, Llimbs, P->Le, P->Llimbs, h->Lnz, h->Lnl))) return e;
-    if ((Ulen || Ulimbs) && (e = fetch_factor(Ulen, Ulimbs, P->Ue, P->Ulimbs, h->Unz, h->Unl))) return e;
+    if ((Llen || Llimbs) && (e = fetch_factor(Llen, Llimbs, f->rescaled ? f->rsLe : P->Le, f->rescaled ? f->rsLl : P->Llimbs, h->Lnz, f->rescaled ? f->rsLnl : h->Lnl))) return e;
+    if ((Ulen || Ulimbs) && (e = fetch_factor(Ulen, Ulimbs, f->rescaled ? f->rsUe : P->Ue, f->rescaled ? f->rsUl : P->Ulimbs, h->Unz, f->rescaled ? f->rsUnl : h->Unl))) return e;
     if (pinv) CK(hipMemcpy(pinv, P->pinv, (size_t) f->n * 4, hipMemcpyDeviceToHost));
     if ((rholen || rholimbs) && K > 0) {
-        /* the pivots live in the L slab: gather them through the pivot records */
+        /* the pivots live in the L slab: gather them through the pivot records (a rescaled copy: through the pivot entries) */
         SlipPiv *pr = (SlipPiv *) malloc((size_t) K * sizeof(SlipPiv));
         if (!pr) return SLIP_HIP_OUT_OF_MEMORY;
         if (hipMemcpy(pr, P->piv, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(pr); return SLIP_HIP_DEVICE_ERROR; }
+        const uint64_t *Lsrc = P->Llimbs;
+        if (f->rescaled) {
+            int64_t *pi = (int64_t *) malloc((size_t) K * 8);
+            SlipEnt pe;
+            if (!pi) { free(pr); return SLIP_HIP_OUT_OF_MEMORY; }
+            int bad = hipMemcpy(pi, f->rspiv, (size_t) K * 8, hipMemcpyDeviceToHost) != hipSuccess;
+            for (int32_t k = 0; k < K && !bad; k++) {
+                if (hipMemcpy(&pe, f->rsLe + pi[k], sizeof pe, hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+                pr[k].off = pe.off; pr[k].len = pe.len;
+            }
+            free(pi);
+            if (bad) { free(pr); return SLIP_HIP_DEVICE_ERROR; }
+            Lsrc = f->rsLl;
+        }
         int64_t o = 0, capl = rho_limbs_inout ? *rho_limbs_inout : 0;
         int rc = 0;
         for (int32_t k = 0; k < K && !rc; k++) {
@@ -989,7 +1195,7 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
             if (rholen) rholen[k] = d < 0 ? -l : l;
             if (rholimbs) {
                 if (o + l > capl) { rc = SLIP_HIP_INCORRECT_INPUT; break; }
-                if (hipMemcpy(rholimbs + o, P->Llimbs + pr[k].off, (size_t) l * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+                if (hipMemcpy(rholimbs + o, Lsrc + pr[k].off, (size_t) l * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
             }
             o += l;
         }

@@ -188,3 +188,105 @@ def assemble_blocks(blocks, q, local):
         out["L"].append({ids[r]: v * sigma[k] for r, v in l["L"][kl].items()})
         out["U"].append({ids[r]: v * sigma[pos_of_row[ids[r]]] for r, v in l["U"][kl].items()})
     return out
+
+
+def leading_blocks(n, Ap, Ai, q, t):
+    """Independent subtrees of the LEADING t columns of the elimination order (the column elimination tree is
+    not given by the reference -- SLIP_LU_analyze returns only q -- so the subtrees are found as the connected components of
+    the row/column graph of columns q[0:t]).  A component can be factorised on its own, with the block's local pivot chain,
+    when its row-id set equals its column-id set (the reference's diagonal pivot test reads row id == column id,
+    slip_get_pivot.c:96).  Returns (blocks, rest): blocks[b] = sorted ids of a farmable component, rest = the columns of
+    q that belong to no such component (the top separator: they stay with rank 0), in elimination order.
+    t = n on a block-diagonal matrix gives diagonal_blocks()."""
+    q = [int(c) for c in q]
+    lead = q[:t]
+    parent = {}
+
+    def find(a):
+        while parent.setdefault(a, a) != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for j in lead:
+        for p in range(int(Ap[j]), int(Ap[j + 1])):
+            a, b = find(("c", j)), find(("r", int(Ai[p])))
+            if a != b:
+                parent[a] = b
+    comps = {}
+    for j in lead:
+        comps.setdefault(find(("c", j)), [set(), set()])[0].add(j)
+    for key in list(parent):
+        if key[0] == "r":
+            root = find(key)
+            if root in comps:
+                comps[root][1].add(key[1])
+    blocks = sorted(sorted(cs) for cs, rs in comps.values() if cs == rs)
+    inblock = set(g for b in blocks for g in b)
+    rest = [c for c in q if c not in inblock]
+    return blocks, rest
+
+
+def farm_factorize(dist, n, Ap, Ai, Ax, q, blocks, kcols=0, device="cpu", make=None, **kw):
+    """The subtree farm's data path on this rank (one process per GPU): factorise this rank's share of the independent
+    blocks on the device, exchange the blocks' pivot chains with ONE all-gather (RCCL on `device`="cuda" tensors under the
+    nccl backend; gloo on CPU tensors in the tests), form the scales, rescale this rank's columns on the device
+    (slip_hip_factor_rescale) and download them.  kcols > 0: only the first kcols columns of every block (a column window).
+    Returns (mine, owner, sigma): mine[t] = canonical factor dict of block t (values already global), owner[k] = block of
+    the k-th committed global column, sigma[k] its scale."""
+    import slip_lu_amd as sl
+    rank, world, _ = env_rank()
+    bins = lpt_partition([len(b) ** 2 for b in blocks], world)
+    handles, ncols = {}, {}
+    for t in bins[rank]:
+        ids = blocks[t]
+        bp, bi, bx, bq = extract_block(ids, Ap, Ai, Ax, q)
+        alen, alimbs = sl.ints_to_slab(np.array(bx, dtype=np.int64))
+        f = (make or sl.Factorization)(len(ids), bp, bi, alen, alimbs, bq, **kw)
+        f.run(kcols)
+        handles[t] = f
+    # the exchange: every rank's pivot chains (packed big integers), tagged by the columns each block committed
+    lens, limbs, counts = [], [], []
+    for t in sorted(handles):
+        d = handles[t].download()
+        lens += [int(v) for v in d["rholen"]]; limbs += [int(v) for v in d["rholimbs"]]
+        counts.append(d["K"])
+    # (the column counts travel in a second, tiny gather so that the packed format stays "big integers only")
+    cnt = allgather_bigints(dist, [1 if c else 0 for c in counts], [c for c in counts if c], device=device)
+    chains_g = allgather_bigints(dist, lens, limbs, device=device)
+    chains, done_cols = {}, {}
+    for r in range(len(chains_g)):
+        vals = _to_ints(*chains_g[r])
+        cvals = _to_ints(*cnt[r])
+        o = 0
+        for t, c in zip(sorted(bins[r]), cvals):
+            chains[t] = vals[o:o + c]; done_cols[t] = c; o += c
+    block_of = {g: t for t, ids in enumerate(blocks) for g in ids}
+    seen = [0] * len(blocks)
+    owner = []
+    for c in q:
+        t = block_of.get(int(c))
+        if t is None:
+            continue
+        if seen[t] < done_cols[t]:
+            owner.append(t)
+        seen[t] += 1
+    sigma = subtree_scales(owner, [chains[t] for t in range(len(blocks))])
+    # this rank rescales ITS columns on the device: local column kl of block t is the kl-th global column owned by t
+    glob = {t: [k for k, o_ in enumerate(owner) if o_ == t] for t in handles}
+    mine = {}
+    for t, f in handles.items():
+        f.rescale([sigma[k] for k in glob[t]])
+        mine[t] = f.download()
+        f.close()
+    return mine, owner, sigma
+
+
+def _to_ints(lens, limbs):
+    out, o = [], 0
+    for l in lens:
+        a = 0
+        for t in range(abs(int(l))):
+            a |= int(limbs[o + t]) << (64 * t)
+        o += abs(int(l))
+        out.append(-a if l < 0 else a)
+    return out

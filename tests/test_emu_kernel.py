@@ -80,3 +80,38 @@ def test_emulated_solve_zero_and_unit_rhs(emu_lib):
     finally:
         g.close()
     assert oracle_lib.bigints(*x2) == x
+
+
+def check_rescale(lib_path, name, seed, **kw):
+    """slip_hip_factor_rescale (subtree farm): every stored value times its column's / its row's pivot
+    position's scale, against python integers"""
+    import numpy as np
+    import oracle_lib
+    import slip_lu_amd as sl
+    entry, fix = load_case(name)
+    n = entry["n"]
+    f = sl.Factorization(n, fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], lib_path=lib_path, **kw)
+    try:
+        f.run(0)
+        before = f.download()
+        rng = np.random.default_rng(seed)
+        scales = [int(rng.integers(1, 2 ** 62)) ** int(rng.integers(1, 5)) * (1 if rng.random() < 0.5 else -1) for _ in range(n)]
+        f.rescale(scales)
+        after = f.download()
+    finally:
+        f.close()
+    pinv = before["pinv"]
+    L0 = oracle_lib.bigints(before["Llen"], before["Llimbs"]); L1 = oracle_lib.bigints(after["Llen"], after["Llimbs"])
+    U0 = oracle_lib.bigints(before["Ulen"], before["Ulimbs"]); U1 = oracle_lib.bigints(after["Ulen"], after["Ulimbs"])
+    r0 = oracle_lib.bigints(before["rholen"], before["rholimbs"]); r1 = oracle_lib.bigints(after["rholen"], after["rholimbs"])
+    assert np.array_equal(before["Li"], after["Li"]) and np.array_equal(before["Ui"], after["Ui"])
+    for k in range(n):
+        for p in range(int(before["Lp"][k]), int(before["Lp"][k + 1])):
+            assert L1[p] == L0[p] * scales[k], ("L", k, p)
+        for p in range(int(before["Up"][k]), int(before["Up"][k + 1])):
+            assert U1[p] == U0[p] * scales[int(pinv[int(before["Ui"][p])])], ("U", k, p)
+        assert r1[k] == r0[k] * scales[k], ("rho", k)
+
+
+def test_emulated_rescale(emu_lib):
+    check_rescale(emu_lib, "gen_n40", 5, waves=2, workers=2)

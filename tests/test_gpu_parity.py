@@ -173,6 +173,26 @@ def test_gpu_wave_reductions():
             assert (out[64 * t:64 * t + 64] == fn(a[64 * t:64 * t + 64])).all(), (op, t)
 
 
+def test_gpu_farm_device_path():
+    """SURVEY 8(e) end to end on the device: blocks factorised by the HIP path, pivot chains exchanged (world 1 here),
+    columns rescaled by slip_hip_factor_rescale, equal to the HIP factorisation of the whole matrix"""
+    import slip_lu_amd as sl
+    import test_subtree_farm as T
+
+    def whole(n, Ap, Ai, Ax, q):
+        Alen, Alimbs = sl.ints_to_slab(Ax)
+        return sl.factorize(n, Ap, Ai, Alen, Alimbs, q)
+    T.farm_vs_whole(whole, None)
+    T.farm_vs_whole(whole, None, sizes=(40, 25, 60, 33), seed=5)
+
+
+@pytest.mark.parametrize("name", ["gen_n40", "prob159", "gen_n300"])
+def test_gpu_rescale_kernel(name):
+    """the farm's device rescale (one wavefront per stored entry; products up to several hundred digits)"""
+    from test_emu_kernel import check_rescale
+    check_rescale(None, name, 11)
+
+
 def test_gpu_subtree_farm_law():
     """independent diagonal blocks factorised one by one on the HIP path and reassembled with
     slip_lu_amd.parallel (pivot chains -> scales) equal the HIP factorisation of the whole matrix."""
@@ -200,6 +220,23 @@ def test_gpu_worker_count_independent(name, kw):
     res = _run(entry, fix, **kw)
     assert res["status"] == entry["status"]
     check_against_golden(entry, fix, res)
+
+
+def test_gpu_tied_pivots_under_load():
+    """fome12 has columns whose best pivot candidates tie in magnitude over several limbs: the exact comparison of the early
+    commit runs while other waves are busy (a race here once published one row and copied the other); ten runs, two shapes"""
+    import slip_lu_amd as sl
+    import slabfile
+    entry, fix = load_case("fome12")
+    for workers in (32, 0):
+        f = sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], workers=workers)
+        try:
+            for rep in range(5):
+                f.reset(); f.run()
+                got = f.download()
+                assert np.array_equal(got["pinv"], fix["pinv"]) and slabfile.factor_digest(got) == entry["digest"], (workers, rep)
+        finally:
+            f.close()
 
 
 def test_gpu_limb_mac_counter_matches_oracle():

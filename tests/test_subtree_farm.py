@@ -96,7 +96,8 @@ WORKER = textwrap.dedent('''
     rank, world, _ = parallel.env_rank()
     n, Ap, Ai, Ax = T.make_blocked((4, 6, 3, 5), 31)
     q = np.random.default_rng(32).permutation(n).astype(np.int32)
-    blocks = parallel.diagonal_blocks(n, Ap, Ai)
+    blocks, rest = parallel.leading_blocks(n, Ap, Ai, q, n)          # components of the leading columns' graph
+    assert rest == [] and blocks == parallel.diagonal_blocks(n, Ap, Ai)
     bins = parallel.lpt_partition([len(b) ** 3 for b in blocks], world)
     mine = {{}}
     for t in bins[rank]:
@@ -148,3 +149,74 @@ def test_farm_exchange_two_ranks_gloo():
     import json
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res == dict(ok=2, world=2)
+
+
+def test_leading_blocks_detection():
+    """components of the LEADING columns only: a prefix of the order may decouple where the whole matrix does not"""
+    n, Ap, Ai, Ax = make_blocked((4, 6, 3, 5), 31)
+    q = np.random.default_rng(32).permutation(n).astype(np.int32)
+    blocks, rest = parallel.leading_blocks(n, Ap, Ai, q, n)
+    assert blocks == parallel.diagonal_blocks(n, Ap, Ai) and rest == []
+    # couple everything through one extra dense LAST column: the whole matrix is one component, its leading n-1 columns are not
+    last = int(q[-1])
+    cols = [[(int(Ai[p]), int(Ax[p])) for p in range(Ap[j], Ap[j + 1])] for j in range(n)]
+    cols[last] = [(i, 1 + i) for i in range(n)]
+    Ap2, Ai2 = [0], []
+    for j in range(n):
+        Ai2 += [i for i, _ in cols[j]]; Ap2.append(len(Ai2))
+    Ap2, Ai2 = np.array(Ap2, np.int64), np.array(Ai2, np.int32)
+    assert parallel.diagonal_blocks(n, Ap2, Ai2) in (None, [sorted(range(n))])
+    lead, rest = parallel.leading_blocks(n, Ap2, Ai2, q, n - 1)
+    assert rest and rest[-1] == last
+    assert all(set(b) <= set(range(n)) - {last} for b in lead) and len(lead) >= 2
+
+
+def farm_vs_whole(factor_whole, make, sizes=(3, 5, 4), seed=7, kcols=0, **kw):
+    """slip_lu_amd.parallel.farm_factorize (blocks on the device, pivot chains exchanged, columns rescaled ON THE DEVICE)
+    against the factorisation of the whole matrix: same pivots, same values entry by entry"""
+    n, Ap, Ai, Ax = make_blocked(sizes, seed)
+    q = np.random.default_rng(seed + 1).permutation(n).astype(np.int32)
+    whole = as_columns(factor_whole(n, Ap, Ai, Ax, q))
+    blocks, rest = parallel.leading_blocks(n, Ap, Ai, q, n)
+    assert rest == []
+    mine, owner, sigma = parallel.farm_factorize(None, n, Ap, Ai, Ax, q, blocks, kcols=kcols, make=make, **kw)
+    assert any(s != 1 for s in sigma)
+    done = [0] * len(blocks)
+    for k, t in enumerate(owner):
+        kl = done[t]; done[t] += 1
+        loc = as_columns_partial(mine[t])
+        ids = blocks[t]
+        assert loc["rho"][kl] == whole["rho"][k], k
+        assert {ids[r]: v for r, v in loc["L"][kl].items()} == whole["L"][k], k
+        assert {ids[r]: v for r, v in loc["U"][kl].items()} == whole["U"][k], k
+
+
+def as_columns_partial(r):
+    K = r["K"]
+    Lx = oracle_lib.bigints(r["Llen"], r["Llimbs"]); Ux = oracle_lib.bigints(r["Ulen"], r["Ulimbs"])
+    rho = oracle_lib.bigints(r["rholen"], r["rholimbs"])
+    L = [{int(r["Li"][p]): Lx[p] for p in range(r["Lp"][k], r["Lp"][k + 1])} for k in range(K)]
+    U = [{int(r["Ui"][p]): Ux[p] for p in range(r["Up"][k], r["Up"][k + 1])} for k in range(K)]
+    return dict(rho=rho, L=L, U=U)
+
+
+def test_farm_device_path_on_emulator():
+    """the farm's device path (factorise blocks, rescale on the device) with the CPU emulation build of the kernel source"""
+    import slip_lu_amd as sl
+    emu = os.path.join(ROOT, "tests", "emu", "libslip_emu.so")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libslip_emu.so"])
+
+    def make(n, Ap, Ai, Alen, Alimbs, q, **kw):
+        return sl.Factorization(n, Ap, Ai, Alen, Alimbs, q, lib_path=emu, waves=1, workers=2, **kw)
+    farm_vs_whole(oracle_factor, make)
+
+
+def test_bench_builds_the_torchrun_command():
+    """bench.py --gpus 2 without a torchrun environment starts one rank per GPU as a child process"""
+    sys.path.insert(0, ROOT)
+    import bench
+    args = type("A", (), dict(gpus=2, steps=3, warmup=1, no_cpu_baseline=True, no_secondary=True))()
+    cmd = bench.relaunch_distributed(args)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--gpus") + 1] == "2" and "--no-cpu-baseline" in cmd and os.path.basename(cmd[cmd.index("--gpus") - 1]) == "bench.py"
