@@ -82,7 +82,7 @@ typedef struct SlipState {
     int64_t Lnz, Lnl, Unz, Unl;                     /* mirrors of Lp/Lo/Up/Uo at the frontier (written at kernel end)     */
     int64_t Lnl_exact, Unl_exact;                   /* limbs actually stored                                             */
     int64_t out_used;                               /* solve: limbs of the output slab in use                            */
-    unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig, c_macs;
+    unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig, c_macs, c_short;    /* c_short: columns committed by the short chain */
     unsigned long long prof[24];                    /* -DSLIP_PROFILE_PHASES builds only */
 } SlipState;
 
@@ -107,7 +107,10 @@ typedef struct SlipParams {
     int32_t k0, t0;                                 /* ticket t0 + d is column k0 + d in this launch                    */
     int32_t bitmap_in_lds, scratch_in_lds;          /* where the bitmap / wave scratch live (generic kernel)            */
     int32_t nworkers, worker;
-    int32_t no_early, pad_e;                        /* diagnostics: 1 = every column takes the complete path (no early commit) */
+    int32_t no_early;                               /* diagnostics: 1 = every column takes the complete path (no early commit) */
+    int32_t committer;                              /* 1: block 0 of the launch is the committer (ref_lu_pipe_commit.h), the others are column workers */
+    uint32_t *pkg;                                  /* shared: one package slot per worker (SLIP_PKG_WORDS words each)      */
+    int32_t *sw_row, *sw_pos;                       /* shared: the swap log -- column c's pivot changed places with row sw_row[c] (= row_perm[c] before), which moved to position sw_pos[c] (= the pivot row's position before) */
     int64_t priv_rows;                              /* rows per worker of the private arrays (= n)                      */
     int32_t *dbg;
 } SlipParams;
@@ -155,7 +158,23 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
        SV_LALLOC = 16 /* limbs of the L slab handed out to this column's direct rows */, SV_LEXACT = 18,
        SV_NROWS = 24 /* rows discovered so far (length of rlist) */, SV_K = 25, SV_TAG = 26, SV_ABORT = 27,
        SV_TMP2 = 28, SV_F2 = 29 /* ready frontier as this worker knows it */, SV_TMP3 = 30, SV_ACNT = 31 /* class-A rows of the early commit (zeroed at column start) */,
-       SV_EPR = 32, SV_EPP = 33, SV_EST = 34 /* early commit: pivot row, its position, status (written by wave 0) */ };
+       SV_EPR = 32, SV_EPP = 33, SV_EST = 34 /* early commit: pivot row, its position, status (written by wave 0) */,
+       SV_PP = 36 /* SLIP_PP_WORDS words: what the pre-pass of the commit chain found (slip_prepass) */,
+       SV_PKGVER = 60 /* version of this worker's exported package (0: none yet) */, SV_PKGX = 61 /* 1: exported and still valid */,
+       SV_PKGF = 62 /* the frontier the package's positions were read at */ };
+#define SLIP_PP_WORDS  14
+/* a column's package for the committer (ref_lu_pipe_commit.h), offsets in 32-bit words */
+#define SLIP_PKG_CANDS   16       /* a package lists at most this many candidates ... */
+#define SLIP_PKG_NROWMAX 256      /* ... of a pattern of at most this many rows */
+#define SLIP_PKG_HDR     0        /* 64-bit {k+1, version}: 1 being written, 2 valid, 3 retracted */
+#define SLIP_PKG_STAMP   2
+#define SLIP_PKG_NROWS   3
+#define SLIP_PKG_SUMS    4        /* SLIP_PP_WORDS words */
+#define SLIP_PKG_STAMP0  18
+#define SLIP_PKG_OUT     32       /* the outcome: a 128-byte line of its own */
+#define SLIP_PKG_CAND    64       /* 5 words per candidate */
+#define SLIP_PKG_ROWS    160
+#define SLIP_PKG_WORDS   448
 
 SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
 SLIP_DEV int slip_abs(int32_t v) { return v < 0 ? -v : v; }
@@ -1030,5 +1049,6 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
 }
 
 #include "ref_lu_pipe_cols.h"
+#include "ref_lu_pipe_commit.h"
 
 #endif /* SLIP_REF_LU_PIPE_H */

@@ -13,11 +13,16 @@
 #endif
 #define SLIPDEV_ABORTED 100                 /* internal to the kernel: this worker's column can never commit */
 
+/* the worker's side of the committer protocol (ref_lu_pipe_commit.h) */
+SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *lds, const int Fl);
+SLIP_DEV void slip_retract_package(const SlipParams &P, const int k, volatile int32_t *sv);
+
 SLIP_DEV void slip_raise_stop(SlipState *st, int k, int status) { slip_agent_min_i64(&st->stop, ((int64_t) k << 8) | (int64_t) status); }
 
 /* Wait until the commit frontier reaches `need` (need <= k).  Called by all threads; returns the frontier, or -1 when
- * column k can never commit (an earlier column stopped the factorisation, or a wait timed out). */
-SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k)
+ * column k can never commit (an earlier column stopped the factorisation, or a wait timed out).  once: one look only
+ * (the frontier as it is, possibly below `need`). */
+SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, int once = 0)
 {
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     slip_block_sync();
@@ -28,6 +33,7 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k)
             int pr;
             const int F = slip_ld_frontier(st, &pr);
             if (F >= need) { res = F; sv[SV_TMP3] = pr; break; }       /* pr = row_perm[F-1], for free */
+            if (once) { res = F; break; }                               /* a look, not a wait: the caller has something to do meanwhile */
             const int64_t stop = slip_ld_i64(&st->stop);
             if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             /* the further from its turn, the longer between polls: the frontier word is one line for the whole chip */
@@ -95,6 +101,122 @@ SLIP_DEV void slip_rlist_push(const SlipParams &P, volatile int32_t *sv, uint32_
 }
 
 /* ------------------------------------------------------------------ */
+/* The pre-pass of the commit chain.  When a column's sweep has run dry and the frontier is still below k, everything the
+ * pivot choice needs EXCEPT rho[k-1] is already known: which rows are pivotal, the rows' states, rho[h] of the rows that
+ * were updated.  The final values are x * rho[k-1] / rho[h]: rho[k-1]'s bit length shifts every bound by the same amount,
+ * so WHICH rows can be the pivot (bound against bound) does not depend on it.  The pre-pass classifies the rows, adds up
+ * what the capacity checks need and lists the candidates; when the frontier arrives, one wave only has to multiply the
+ * listed candidates, search among them and publish (slip_do_column, "the short commit chain").  Any source applied
+ * afterwards invalidates it (sv[SV_PP] = 0: the sweep does that).
+ * Row table entry f_inf = class | (c + SLIP_PP_BIAS) << 2 with  bits(value) <= c + bits(rho[k-1]):
+ *   class 0: pivotal or zero; 2: never updated, one limb (S: lane product or straight into the L slab, slot handed out
+ *   here); 3: anything else (B: a wave item at commit time).
+ * sv[SV_PP + ..]: 0 valid, 1 candidates, 2 S rows, 3 pivotal rows, 4 their limbs, 5 limb bound of the B rows (without
+ * rho[k-1]'s share), 6 B rows, 7 largest c of a B row (biased), 8 largest ctz of their rho[h], 9 largest c (biased),
+ * 10 longest pivotal row (bits), 11 best bound, 12 candidates that are not class S, 13 table index + 1 of the diagonal row
+ * when it is a candidate.  Called by all threads; barriers inside. */
+#define SLIP_PP_BIAS   (1 << 20)
+#define SLIP_PP_CAND   64               /* one candidate per lane of the committing wave */
+SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint32_t *lds, const int Fl)
+{
+    const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    uint32_t *f_row = lds + SLIP_LDS_TAB, *f_pos = f_row + SLIP_TAB_CAP, *f_inf = f_row + 2 * SLIP_TAB_CAP, *f_aux = f_row + 3 * SLIP_TAB_CAP;
+    uint32_t *f_k0 = lds + SLIP_LDS_KEYS, *f_k1 = f_k0 + SLIP_PAT_CAP;
+    uint32_t *cl = lds + SLIP_LDS_WORK + SLIP_CAND_CAP;
+    const int scheme = P.pivot_scheme;
+    const int kind = (scheme == 4 || scheme == 5) ? 1 : 0;            /* 0 smallest, 1 largest (first-nonzero does not come here) */
+    const int diagpref = scheme == 1 || scheme == 3 || scheme == 4;
+    const int col = P.q[k];
+    const int nrows = sv[SV_NROWS];
+    if (tid < SLIP_PP_WORDS) sv[SV_PP + tid] = tid == 11 && kind == 0 ? 0x7FFFFFFF : 0;
+    slip_block_sync();
+    uint32_t ulimbs = 0, nUc = 0, sB = 0, nB = 0, maxcB = 0, maxzh = 0, maxc = 0, maxubp = 0;
+    uint32_t best = kind == 0 ? 0x7FFFFFFFu : 0u;
+    for (int t0 = 0; t0 < nrows; t0 += T) {
+        const int t = t0 + tid;
+        int cls = 0, c = 0, isS = 0, r = 0; uint32_t asgn = 0;
+        if (t < nrows) {
+            r = (int) f_row[t];
+            const int pos = slip_ld_i32(&P.pinv[r]);
+            const SlipRow xr = P.xrow[r];
+            f_pos[t] = (uint32_t) pos;                      /* as read at a frontier >= Fl: the swap log brings it to column k */
+            if (pos < Fl) { ulimbs += (uint32_t) slip_limbs(xr.len); nUc++; if ((uint32_t) xr.bits > maxubp) maxubp = (uint32_t) xr.bits; }
+            else if (xr.len == 0) cls = 0;
+            else if (xr.h < 0 && slip_abs(xr.len) <= 2) {
+                cls = 2; isS = 1; c = xr.bits;
+                const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                f_k0[t] = (uint32_t) xv; f_k1[t] = (uint32_t)(xv >> 32);
+                asgn = ((uint32_t) slip_abs(xr.len) << 12) | (xr.len < 0 ? 1u << 14 : 0u);
+            } else {
+                cls = 3;
+                int bh = 0, zh = 0;
+                if (xr.h >= 0) { const SlipPiv H = slip_ld_piv(&P.piv[xr.h]); bh = H.bits; zh = H.ctz; }
+                c = xr.bits - bh + (xr.h >= 0 ? 1 : 0);
+                sB += (uint32_t)(((c > 0 ? c : 0) + 63) >> 6) + 1u; nB++;
+                if ((uint32_t)(c + SLIP_PP_BIAS) > maxcB) maxcB = (uint32_t)(c + SLIP_PP_BIAS);
+                if ((uint32_t) zh > maxzh) maxzh = (uint32_t) zh;
+            }
+        }
+        /* S rows get their slots in the L slab now (slot index kept in the row's own x area, behind the value) */
+        const uint64_t am = slip_ballot(isS);
+        int abase = 0;
+        if (lane == 0 && am) abase = slip_atomic_add_i32((int32_t *) &sv[SV_PP + 2], slip_popc64(am));
+        abase = (int) slip_bcast0_u32((uint32_t) abase);
+        if (isS) {
+            const int si = abase + slip_popc64(am & ((1ull << lane) - 1ull));
+            f_aux[t] = (uint32_t) si | asgn;
+            (P.xd + (int64_t) r * P.xcap)[2] = (uint32_t) si;
+        }
+        if (t < nrows) {
+            f_inf[t] = (uint32_t) cls | ((uint32_t)(c + SLIP_PP_BIAS) << 2);
+            if (cls) {
+                const uint32_t ubc = (uint32_t)(c + SLIP_PP_BIAS), lbc = ubc - (cls == 2 ? 1u : 2u);
+                if (kind == 0) { if (ubc < best) best = ubc; } else { if (lbc > best) best = lbc; }
+                if (ubc > maxc) maxc = ubc;
+            }
+        }
+    }
+    {
+        const uint32_t w_u = slip_wave_sum_u32(ulimbs), w_n = slip_wave_sum_u32(nUc), w_s = slip_wave_sum_u32(sB), w_nb = slip_wave_sum_u32(nB);
+        const uint32_t w_cb = slip_wave_max_u32(maxcB), w_zh = slip_wave_max_u32(maxzh), w_c = slip_wave_max_u32(maxc), w_up = slip_wave_max_u32(maxubp);
+        const uint32_t w_b = kind == 0 ? slip_wave_min_u32(best) : slip_wave_max_u32(best);
+        if (lane == 0) {
+            if (w_n) { slip_atomic_add_i32((int32_t *) &sv[SV_PP + 3], (int) w_n); slip_atomic_add_i32((int32_t *) &sv[SV_PP + 4], (int) w_u); }
+            if (w_nb) { slip_atomic_add_i32((int32_t *) &sv[SV_PP + 5], (int) w_s); slip_atomic_add_i32((int32_t *) &sv[SV_PP + 6], (int) w_nb); }
+            slip_atomic_max_i32((int32_t *) &sv[SV_PP + 7], (int) w_cb); slip_atomic_max_i32((int32_t *) &sv[SV_PP + 8], (int) w_zh);
+            slip_atomic_max_i32((int32_t *) &sv[SV_PP + 9], (int) w_c); slip_atomic_max_i32((int32_t *) &sv[SV_PP + 10], (int) w_up);
+            if (kind == 0) slip_atomic_min_i32((int32_t *) &sv[SV_PP + 11], (int) w_b); else slip_atomic_max_i32((int32_t *) &sv[SV_PP + 11], (int) w_b);
+        }
+    }
+    slip_block_sync();
+    const uint32_t bestb = (uint32_t) sv[SV_PP + 11];
+    const int any = sv[SV_PP + 9] != 0;                            /* a nonzero non-pivotal row exists */
+    for (int t0 = 0; t0 < nrows && any; t0 += T) {
+        const int t = t0 + tid;
+        int cand = 0;
+        if (t < nrows) {
+            const uint32_t inf = f_inf[t];
+            const int cls = (int)(inf & 3u);
+            if (cls) {
+                const uint32_t ubc = inf >> 2, lbc = ubc - (cls == 2 ? 1u : 2u);
+                cand = kind == 0 ? lbc <= bestb : ubc >= bestb;
+                if (diagpref && (int) f_row[t] == col) { cand = 1; sv[SV_PP + 13] = t + 1; }
+                if (cand && cls != 2) sv[SV_PP + 12] = 1;
+            }
+        }
+        const uint64_t mC = slip_ballot(cand);
+        int bC = 0;
+        if (lane == 0 && mC) bC = slip_atomic_add_i32((int32_t *) &sv[SV_PP + 1], slip_popc64(mC));
+        bC = (int) slip_bcast0_u32((uint32_t) bC);
+        if (cand) { const int at = bC + slip_popc64(mC & ((1ull << lane) - 1ull)); if (at < SLIP_PP_CAND) cl[at] = (uint32_t) t; }
+    }
+    slip_block_sync();
+    if (tid == 0) sv[SV_PP] = any && sv[SV_PP + 1] >= 1 && sv[SV_PP + 1] <= SLIP_PP_CAND;
+    slip_block_sync();
+}
+
+/* ------------------------------------------------------------------ */
 /* The ascending sweep over the pivotal positions < k of the pattern (slip_REF_triangular_solve.c:124-241).
  * GATED (a column of the factorisation running ahead of the commit frontier): a source at position jn is
  * applied once jn is below the frontier this worker knows (sv[SV_F]) and L(:,jn) is published; when no such
@@ -113,6 +235,9 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
     uint32_t *work = lds + SLIP_LDS_WORK;
     int cur = -1, step = 0;
     (void) t_wait; (void) t_last;
+    /* the pre-pass of the commit chain runs when the sweep is dry and the frontier has not moved (slip_prepass) */
+    const bool pp_want = GATED && k >= 1 && !P.no_early && P.pivot_scheme != 2 && slip_nwaves() >= 2;
+    int pp_fresh = 0;                            /* the pre-pass describes the rows as they are now */
     int pj = -1, pjn = -1;                       /* the source whose queued (wave) updates are pending */
     int dj = -1, dys = 1, dh = -1;               /* finalised one-limb source value not yet written back */
     slip_u128 dy = 0;
@@ -136,7 +261,28 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
 #ifdef SLIP_PROFILING
             const unsigned long long tw0_ = slip_clock();
 #endif
-            int Fn = slip_wait_frontier(st, lds, Fl + 1, k);
+            int Fn;
+            /* still dry: the exported package holds for every pivot below the frontier this worker knows */
+            if (GATED && pp_fresh && tid == 0 && sv[SV_PKGX]) slip_st_u32(P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_STAMP, (uint32_t) Fl);
+            if (pp_want && !pp_fresh && sv[SV_NROWS] <= SLIP_TAB_CAP) {
+                Fn = slip_wait_frontier(st, lds, Fl + 1, k, 1);
+                if (Fn >= 0 && Fn <= Fl) {       /* nothing to do but wait: classify the rows and list the pivot candidates meanwhile */
+                    slip_prepass(P, k, tag, lds, Fl);
+                    pp_fresh = 1;
+                    /* a column whose candidates are all one-limb values is handed to the committer */
+#ifdef SLIP_EMU_TRACE
+                    if (tid == 0) fprintf(stderr, "worker: col %d prepass valid %d ncand %d nonS %d nrows %d committer %d\n", k, (int) sv[SV_PP], (int) sv[SV_PP + 1], (int) sv[SV_PP + 12], (int) sv[SV_NROWS], P.committer);
+#endif
+                    if (P.committer && sv[SV_PP] && !sv[SV_PP + 12] && !sv[SV_PKGVER] && sv[SV_NROWS] <= SLIP_PKG_NROWMAX && sv[SV_PP + 1] <= SLIP_PKG_CANDS) {
+                        if (tid == 0) sv[SV_PKGF] = Fl;
+                        slip_export_package(P, k, lds, Fl);
+#ifdef SLIP_PROFILING
+                        if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 1] = (int32_t) slip_realtime();  /* time line 1: package exported */
+#endif
+                    }
+                    Fn = slip_wait_frontier(st, lds, Fl + 1, k);
+                }
+            } else Fn = slip_wait_frontier(st, lds, Fl + 1, k);
 #ifdef SLIP_PROFILING
             *t_last = slip_clock(); t_wait[0] += *t_last - tw0_; t_wait[2] = slip_realtime();
 #endif
@@ -147,9 +293,23 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
             if (nr <= SLIP_TAB_CAP) {
                 /* the rows of the pattern are listed in LDS: every thread looks at its share for each new pivot row */
                 const uint32_t *lrow = lds + SLIP_LDS_TAB;
-                for (int c = Fl; c < Fn; c++) {
-                    const int r = c == Fseen - 1 ? prow : slip_ld_i32(&P.row_perm[c]);
-                    for (int t = tid; t < nr; t += T) if ((int) lrow[t] == r) slip_atomic_or_u32(&bm[c >> 5], 1u << (c & 31));
+                if (Fn - Fl == 1 && Fseen == Fn) {
+                    for (int t = tid; t < nr; t += T) if ((int) lrow[t] == prow) slip_atomic_or_u32(&bm[Fl >> 5], 1u << (Fl & 31));
+                } else {
+                    /* several columns at once (the committer moves the frontier in batches; a worker far from its turn polls
+                     * rarely): the new pivot rows come in ONE round of loads through the part of the work area the sweep
+                     * does not use, not one dependent load per column */
+                    uint32_t *pv = work + 4 * SLIP_WORK_CAP;
+                    for (int c0 = Fl; c0 < Fn; c0 += 2 * SLIP_WORK_CAP) {
+                        const int nc = Fn - c0 < 2 * SLIP_WORK_CAP ? Fn - c0 : 2 * SLIP_WORK_CAP;
+                        slip_block_sync();
+                        for (int e = tid; e < nc; e += T) pv[e] = (uint32_t) slip_ld_i32(&P.row_perm[c0 + e]);
+                        slip_block_sync();
+                        for (int t = tid; t < nr; t += T) {
+                            const uint32_t r = lrow[t];
+                            for (int e = 0; e < nc; e++) if (pv[e] == r) slip_atomic_or_u32(&bm[(c0 + e) >> 5], 1u << ((c0 + e) & 31));
+                        }
+                    }
                 }
             } else
                 for (int c = Fl + tid; c < Fn; c += T) {
@@ -160,6 +320,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
             continue;
         }
         cur = jn;
+        if (GATED && pp_fresh) { pp_fresh = 0; if (tid == 0) { sv[SV_PP] = 0; if (sv[SV_PKGX]) slip_retract_package(P, k, sv); } }      /* this source changes the rows */
         if (GATED && jn >= sv[SV_F2]) {
             /* the source is committed but its L column may still be on its way (stage 2 of column jn) */
 #ifdef SLIP_PROFILING
@@ -377,10 +538,13 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     unsigned long long c_read = 0, c_upd = 0, c_src = 0, c_str = 0, c_mac = 0;
     SLIP_STAMP_INIT();
 
+#ifdef SLIP_PROFILING
+    if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k] = (int32_t) slip_realtime();              /* time line 0: the column starts */
+#endif
     /* ---- phase 0: clear the pattern bitmap, take a snapshot of the commit frontier ---- */
     for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
     if (tid == 0) {
-        sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv[SV_NROWS] = 0; sv[SV_ACNT] = 0;
+        sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv[SV_NROWS] = 0; sv[SV_ACNT] = 0; sv[SV_EST] = -1; sv[SV_PP] = 0; sv[SV_PKGX] = 0; sv[SV_PKGVER] = 0;
         sv64[SV_LALLOC / 2] = 0; sv64[SV_LEXACT / 2] = 0;
         /* the ready frontier first: it never passes the commit frontier, also not between the two loads */
         sv[SV_F2] = slip_ld_i32(&st->F2);
@@ -449,16 +613,59 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     const bool try_early = k >= 1 && nrows <= SLIP_FAST_CAP && !P.no_early;
     /* the first round of loads of the commit chain: everything is issued before anything is waited for -- this thread's
      * row (its position and state), then rho[k-1]'s record, and the column cursors by six lanes of the last wave */
+    /* the short commit chain: the pre-pass (slip_prepass, run while this worker waited) still describes the rows, so wave 0
+     * alone multiplies the listed candidates, searches and publishes while the other waves take the position snapshot */
+    /* a column whose package the committer holds: wait for the verdict (the outcome word of the package: this worker's
+     * own line, not the frontier) */
+    int adopted = 0;
+#ifdef SLIP_PROFILING
+    if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 5] = (int32_t) slip_realtime();          /* time line 5: the sweep has seen F >= k */
+#endif
+    const int packaged = P.committer && try_early && sv[SV_PKGX];
+    slip_block_sync();                                   /* (thread 0 clears the flag below) */
+    if (packaged) {
+        const uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
+        if (tid == 0) {
+            int res; unsigned long long spins = 0;
+            for (;;) {
+                const int v = (int) slip_ld_u32(pk + SLIP_PKG_OUT);
+                if (v == k + 1) { res = 1; break; }
+                if (v == -(k + 1)) { res = 0; break; }
+                const int64_t stop = slip_ld_i64(&st->stop);
+                if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
+                slip_sleep_short();
+                if (++spins > SLIP_SPIN_LIMIT) { slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
+            }
+            sv[SV_TMP2] = res;
+            if (res == 0) sv[SV_PKGX] = 0;               /* rejected: this worker commits the column itself */
+        }
+        slip_block_sync();
+#ifdef SLIP_PROFILING
+        if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 3] = (int32_t) slip_realtime();      /* time line 3: verdict seen */
+#endif
+        if (sv[SV_TMP2] < 0) return SLIPDEV_ABORTED;
+        adopted = sv[SV_TMP2];
+    }
+    const bool fastc = !adopted && try_early && nw >= 2 && sv[SV_PP] != 0;
+    uint32_t *ppcl = work + SLIP_CAND_CAP;                 /* the pre-pass's candidate list (table indices) */
     int r0_ = 0, pos0_ = 0; SlipRow xr0_; xr0_.len = 0; xr0_.h = 0; xr0_.bits = 0; xr0_.tag = 0;
-    if (tid < nrows) {
+    int c_t = -1, c_r = 0, c_pos = 0; SlipRow c_x = xr0_;  /* short chain, wave 0: this lane's candidate */
+    if (fastc) {
+        if (wave == 0 && lane < sv[SV_PP + 1]) {
+            c_t = (int) ppcl[lane]; c_r = (int) f_row[c_t];
+            c_pos = slip_ld_i32(&P.pinv[c_r]);
+            c_x = P.xrow[c_r];
+        }
+    } else if (tid < nrows) {
         r0_ = small ? (int) f_row[tid] : P.rlist[tid];
         pos0_ = slip_ld_i32(&P.pinv[r0_]);
         if (try_early) xr0_ = P.xrow[r0_];
     }
     SlipPiv M = slip_piv_none();
     if (k >= 1) M = slip_ld_piv(&P.piv[k - 1]);
-    {
-        const int q_ = tid - (T - 8);
+    if (adopted) slip_agent_acquire();                   /* what the committer wrote for this column is read below */
+    if (!fastc || wave == 0) {
+        const int q_ = fastc ? lane - (SLIP_WAVE - 8) : tid - (T - 8);
         if (q_ == 0) sv64[SV_LNZ / 2] = slip_ld_i64(&P.Lp[k]);
         else if (q_ == 1) sv64[SV_LNL / 2] = slip_ld_i64(&P.Lo[k]);
         else if (q_ == 2) sv64[SV_UNZ / 2] = slip_ld_i64(&P.Up[k]);
@@ -469,6 +676,341 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     }
     const int lm = slip_abs(M.len), brho = M.bits;
     const int slot = (lm + 3) >> 1;
+    /* rho[k-1]'s digits for the candidate multiplies are staged in LDS */
+    const bool BMs = SCR_LDS && lm <= wcap;
+    dig_t *Ms = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + nw * 3 * wcap : (dig_t *) 0;
+    int pc_col = 0;
+    int early = 0, e_pivrow = -1, e_pivpos = -1;
+#ifdef SLIP_PROFILING
+    unsigned long long tr_t2_ = slip_clock(), tr_sweep_ = t_last_ ? tr_t2_ - t_last_ : 0;
+#endif
+    /* where the digits of a row are: its x row (private), or (rows multiplied straight into L: h == -2) the slab (shared) */
+    auto row_direct = [&](int r) -> int { return P.xrow[r].h == -2; };
+    auto row_digits = [&](int r) -> const dig_t * {
+        const dig_t *X = P.xd + (int64_t) r * P.xcap;
+        return P.xrow[r].h == -2 ? (const dig_t *)(P.Llimbs + *(const int64_t *) X) : X;
+    };
+    /* the tolerance test of the diagonal preference between the best candidate `pr` and the diagonal row `col`
+     * (slip_get_pivot.c:89-118, 126-146): 1 = take the diagonal; *err: scratch too small */
+    auto diag_rule = [&](int pr, int *err) -> int {
+        if (scheme == 1 || P.tol_mode == 0) return 1;
+        const int lp_ = slip_abs(P.xrow[pr].len), lc_ = slip_abs(P.xrow[col].len);
+        /* tol_m has exactly 53 bits, so tol_m*|den| has 52 or 53 bits more than |den|: most columns
+         * are decided by the bit lengths alone */
+        const int te0 = P.tol_e;
+        const int bnum_ = (scheme == 3 ? P.xrow[pr].bits : P.xrow[col].bits) + (te0 < 0 ? -te0 : 0);
+        const int bden_ = (scheme == 3 ? P.xrow[col].bits : P.xrow[pr].bits) + (te0 > 0 ? te0 : 0);
+        if (bnum_ < 52 + bden_) return 0;
+        if (bnum_ > 53 + bden_) return 1;
+        /* exact comparison.  Every wave runs it redundantly in its own scratch.  A row that lives in the L
+         * slab is shared data: its digits are staged (sc1 loads) into scratch the comparison does not need
+         * at that point -- the denominator into b1 (free until the last step, when the denominator has
+         * been consumed), the numerator behind the product in b2. */
+        const int rn = scheme == 3 ? pr : col, rd = scheme == 3 ? col : pr;   /* |small|/|diag| or |diag|/|large| >= tol */
+        const int ln = scheme == 3 ? lp_ : lc_, ldn = scheme == 3 ? lc_ : lp_;
+        const dig_t *num = P.xd + (int64_t) rn * P.xcap, *den = P.xd + (int64_t) rd * P.xcap;
+        if (ldn + 2 > wcap) { *err = 1; return 0; }
+        if (row_direct(rd)) { slip_stage_shared(b1, row_digits(rd), ldn); den = b1; }
+        if (row_direct(rn)) {
+            if (ldn + 4 + ln > wcap) { *err = 1; return 0; }
+            slip_stage_shared(b2 + ldn + 4, row_digits(rn), ln); num = b2 + ldn + 4;
+        }
+        const int tk = slip_tol_compare_out(P.tol_m, P.tol_e, num, ln, den, ldn, b0, b1, b2, wcap);
+        if (tk < 0) { *err = 1; return 0; }
+        return tk;
+    };
+
+    /* ---- the exact search among the candidates and stage 1 of the commit.  ONE wave runs this (the publishing wave rewrites
+     * the pivot row's state: nobody else may be looking at it); the outcome lands in sv[SV_EPR], sv[SV_EPP], sv[SV_EST]. */
+    struct CommitArgs { int ncand, diag_cand, nA, nLc, narith, slotw, sync; uint32_t nUc_all; uint64_t U_l, Lb_total;
+                        int64_t Lnz_, Lnl_, Unz_, Unl_; const uint32_t *cl; };
+    dig_t *stage = lds + SLIP_LDS_PAT;       /* a candidate's product is also left in LDS (slots over the areas phase 3c fills later) */
+    auto search_publish = [&](const CommitArgs &A) {
+            /* the exact search among the candidates (all exact now), slip_get_pivot.c:58-155: (bit length, leading bits)
+             * keys; the candidates that tie on the best key are compared exactly, then by position.  Every wave does the
+             * whole (short) search by itself: lanes = candidates, no workgroup barrier. */
+            auto key_of = [&](int t) -> uint64_t {
+                if (kind == 2) return (uint64_t) f_pos[t];
+                const int cls = (int)(f_inf[t] & 3u);
+                uint64_t key = (uint64_t) f_k0[t] | ((uint64_t) f_k1[t] << 32);
+                if (cls == 3 || (cls == 1 && key == ~0ull)) {          /* value produced by a wave item / final before: key from its digits */
+                    const int r = (int) f_row[t];
+                    const SlipRow xr = P.xrow[r];
+                    const uint64_t top = slip_top64(row_digits(r), slip_abs(xr.len), xr.h == -2);
+                    key = ((uint64_t) xr.bits << 40) | (top >> 24);
+                    if (kind == 1) key = ~key;
+                }
+                return key;
+            };
+            int est = 0;
+            uint64_t mk = ~0ull;
+            for (int c0 = 0; c0 < A.ncand; c0 += SLIP_WAVE) {
+                const int c = c0 + lane;
+                const uint64_t key = c < A.ncand ? key_of((int) A.cl[c]) : ~0ull;
+                /* 64-bit minimum over the wave: the high words first, the low words among the lanes that hold the minimum */
+                const uint32_t mh = slip_wave_min_u32((uint32_t)(key >> 32));
+                const uint32_t ml = slip_wave_min_u32((uint32_t)(key >> 32) == mh ? (uint32_t) key : 0xFFFFFFFFu);
+                const uint64_t wm = ((uint64_t) mh << 32) | ml;
+                if (wm < mk) mk = wm;
+            }
+            int bt = -1;
+            const int kbits = kind == 2 ? 0 : (int)((kind == 0 ? mk : ~mk) >> 40);
+            for (int c0 = 0; c0 < A.ncand; c0 += SLIP_WAVE) {
+                const int c = c0 + lane;
+                const int t = c < A.ncand ? (int) A.cl[c] : -1;
+                uint64_t tie = slip_ballot(t >= 0 && key_of(t) == mk);
+                while (tie) {
+                    const int l = slip_ctz64(tie); tie &= tie - 1;
+                    const int tt = (int) slip_readlane((uint32_t) t, l);
+                    if (bt < 0) { bt = tt; continue; }
+                    const int rb = (int) f_row[bt], rt = (int) f_row[tt];
+                    int cmp = 0;
+                    if (kbits > 40)      /* at most 40 bits: equal keys are equal values */
+                        cmp = slip_cmp_mag(row_digits(rb), row_direct(rb), row_digits(rt), row_direct(rt), slip_abs(P.xrow[rt].len));
+                    if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && f_pos[tt] < f_pos[bt])) bt = tt;
+                }
+            }
+            if (bt < 0) { est = SLIPDEV_INTERNAL; bt = 0; }
+            e_pivrow = (int) f_row[bt]; e_pivpos = (int) f_pos[bt];
+            int stg = (int)((f_inf[bt] >> 26) & 31u) - 1;     /* LDS slot of the pivot's digits, or -1 */
+            /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); col's value is exact: it was a candidate */
+            if (!est && A.diag_cand && e_pivrow != col) {
+                int derr = 0;
+                const int take = diag_rule(e_pivrow, &derr);
+                if (derr) est = SLIPDEV_GROW_X;
+                else if (take) { e_pivrow = col; e_pivpos = pc_col; stg = -1; }
+            }
+            SLIP_STAMP(13);
+            if (A.sync) slip_block_sync_named(1);             /* short chain: the other waves have taken their position snapshot */
+            if (est) { if (lane == 0) sv[SV_EST] = est; }
+            else {
+            SLIP_TR(6);                                       /* 6: search + diag */
+            /* stage 1, early: the pivot's digits written through to the L slab (its class-A slot, or the reserved slot behind
+             * those), the pivot record, the permutation swap, the column pointers (limb offsets from the bounds), ONE
+             * drain, the frontier */
+            SlipRow pxr; int pdirect; int64_t poff;
+            if (stg >= 0) {
+                /* a class-A candidate multiplied a moment ago: everything about it is in LDS */
+                uint64_t key = (uint64_t) f_k0[bt] | ((uint64_t) f_k1[bt] << 32);
+                if (kind == 1) key = ~key;
+                pxr.bits = (int)(key >> 40);
+                const int len_ = (pxr.bits + 31) >> 5;
+                pxr.len = (f_inf[bt] >> 31) ? -len_ : len_; pxr.h = -2; pxr.tag = tag;
+                pdirect = 1; poff = A.Lnl_ + (int64_t)(f_aux[bt] & 0x3FFu) * slot;
+            } else {
+                pxr = P.xrow[e_pivrow];
+                pdirect = pxr.h == -2;
+                poff = pdirect ? *(const int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) : A.Lnl_ + (int64_t) A.nA * slot;
+            }
+            const uint64_t plimbs = (uint64_t) slip_limbs(pxr.len);
+            {
+                const int lp_ = slip_abs(pxr.len);
+                dig_t *dst = (dig_t *)(P.Llimbs + poff);
+                /* where the digits are: the LDS slot the multiplying wave left, the slab (a class-A row that was not staged:
+                 * its stores were drained above), or the row's private x */
+                const dig_t *src = stg >= 0 ? (const dig_t *)(stage + stg * A.slotw) : (pdirect ? (const dig_t *) dst : P.xd + (int64_t) e_pivrow * P.xcap);
+                const int z = slip_publish_digits(dst, src, stg < 0 && pdirect, lp_);
+                const uint64_t lo64 = (stg < 0 && pdirect) ? slip_ld_u64((const uint64_t *) dst) : *(const uint64_t *) src;
+                if (lane == 0) {
+                    SlipPiv pr; pr.off = poff; pr.len = pxr.len; pr.bits = pxr.bits; pr.ctz = z; pr.invlen = 0;
+                    pr.lo = lo64; pr.inv64 = 0; pr.pad = 0;
+                    if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
+                    slip_st_piv(&P.piv[k], pr);
+                    const int intermed = e_pivpos, intermed2 = sv[SV_TMP];
+                    slip_st_i32(&P.row_perm[k], e_pivrow); slip_st_i32(&P.row_perm[intermed], intermed2);
+                    slip_st_i32(&P.pinv[e_pivrow], k); slip_st_i32(&P.pinv[intermed2], intermed);
+                    slip_st_i32(&P.sw_row[k], intermed2); slip_st_i32(&P.sw_pos[k], intermed);
+                    slip_st_i64(&P.Up[k + 1], A.Unz_ + (int) A.nUc_all + 1); slip_st_i64(&P.Lp[k + 1], A.Lnz_ + A.nLc);
+                    slip_st_i64(&P.Uo[k + 1], A.Unl_ + (int64_t)(A.U_l + plimbs)); slip_st_i64(&P.Lo[k + 1], A.Lnl_ + (int64_t) A.Lb_total);
+                }
+                SLIP_TR(7);                                       /* 7: publish stores issued */
+                slip_vm_drain();                                  /* the digits (all lanes) and the records (lane 0) have left */
+                if (lane == 0) {
+                    slip_st_frontier(st, k + 1, e_pivrow);
+#ifdef SLIP_PROFILING
+                    if (t_last_) prof_[18] += slip_clock() - t_last_;
+                    {
+                        int32_t *tr = P.dbg + 8 * (int64_t) k; const unsigned long long nowc = slip_clock();
+                        tr[0] = t_last_ ? (int32_t)(nowc - t_last_) : -1; tr[1] = 1; tr[2] = A.narith; tr[3] = nrows;
+                        tr[4] = (int32_t) tr_sweep_; tr[5] = (int32_t)(nowc - tr_t2_); tr[7] = P.worker;
+                        tr[6] = (int32_t) slip_realtime(); P.dbg[8 * (int64_t) P.n + k] = (int32_t) t_wait_[2];
+                        for (int q_ = 0; q_ < 8; q_++) P.dbg[9 * (int64_t) P.n + 8 * (int64_t) k + q_] = trs_[q_];
+                        P.dbg[9 * (int64_t) P.n + 8 * (int64_t) k + 7] = (int32_t)(nowc - trp_) + trs_[7] * 0;     /* 7b: drain */
+                    }
+#endif
+                    /* from now on the pivot row lives in the slab like a class-A row */
+                    if (!pdirect) {
+                        SlipRow nr = pxr; nr.h = -2; P.xrow[e_pivrow] = nr;
+                        *(int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) = poff;
+                    }
+                    sv64[SV_LALLOC / 2] = (int64_t)((uint64_t) A.nA * (uint64_t) slot + (pdirect ? 0ull : plimbs));
+                    sv[SV_EPR] = e_pivrow; sv[SV_EPP] = e_pivpos; sv[SV_EST] = 0;
+                }
+            }
+            }       /* !est */
+    };
+
+    /* ---- the short commit chain (see slip_prepass) ---- */
+    int ec = -1;                                 /* 0: committed early; > 0: a status; -1: the full pass below decides */
+    if (adopted) {
+        /* the committer has published this column's pivot: take over the outcome and the position snapshot it took */
+        const uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
+        if (BMs) { const dig_t *Mg = slip_piv_digits(P, M); for (int c = tid; c < lm; c += T) Ms[c] = slip_ld_u32(Mg + c); }
+        /* the position snapshot (pinv as the reference has it at column k): the value the pre-pass read at frontier stamp0, or
+         * where the LAST swap in [stamp0, k) that displaced the row put it (positions of non-pivotal rows only ever grow, and a
+         * value read late already shows the swaps before it).  The log goes through LDS in pieces. */
+        {
+            const int stamp0 = sv[SV_PKGF];
+            uint32_t *lg_row = lds + SLIP_LDS_KEYS, *lg_pos = lg_row + SLIP_PAT_CAP;
+            int myr[2] = {-1, -1}, myp[2] = {0, 0};
+            for (int q = 0; q < 2; q++) { const int t = tid + q * T; if (t < nrows) { myr[q] = (int) f_row[t]; myp[q] = (int) f_pos[t]; } }
+            for (int e0 = stamp0; e0 < k; e0 += SLIP_PAT_CAP) {
+                const int ne = k - e0 < SLIP_PAT_CAP ? k - e0 : SLIP_PAT_CAP;
+                slip_block_sync();
+                for (int e = tid; e < ne; e += T) { lg_row[e] = (uint32_t) slip_ld_i32(&P.sw_row[e0 + e]); lg_pos[e] = (uint32_t) slip_ld_i32(&P.sw_pos[e0 + e]); }
+                slip_block_sync();
+                for (int q = 0; q < 2; q++)
+                    if (myr[q] >= 0) for (int e = 0; e < ne; e++) if ((int) lg_row[e] == myr[q]) myp[q] = (int) lg_pos[e];
+            }
+            slip_block_sync();
+            for (int q = 0; q < 2; q++) {
+                const int t = tid + q * T;
+                if (t < nrows) { slip_atomic_or_u32(&bm[myp[q] >> 5], 1u << (myp[q] & 31)); f_pos[t] = (uint32_t) myp[q]; }
+            }
+        }
+        if (tid == 0) {
+            const int pr = (int) slip_ld_u32(pk + SLIP_PKG_OUT + 1);
+            SlipRow nr; nr.len = (int32_t) slip_ld_u32(pk + SLIP_PKG_OUT + 3); nr.h = -2; nr.bits = (int32_t) slip_ld_u32(pk + SLIP_PKG_OUT + 4); nr.tag = tag;
+            P.xrow[pr] = nr;
+            *(int64_t *)(P.xd + (int64_t) pr * P.xcap) = (int64_t) slip_ld_u64((const uint64_t *)(pk + SLIP_PKG_OUT + 6));
+            sv64[SV_LALLOC / 2] = (int64_t) slip_ld_u64((const uint64_t *)(pk + SLIP_PKG_OUT + 8));
+            sv[SV_EPR] = pr; sv[SV_EPP] = (int) slip_ld_u32(pk + SLIP_PKG_OUT + 2);
+        }
+        slip_block_sync();
+        pc_col = sv[SV_TMP3];
+        ec = 0; early = 1; e_pivrow = sv[SV_EPR]; e_pivpos = sv[SV_EPP];
+        SLIP_STAMP(6);
+    }
+    if (fastc) {
+        if (wave == 0) {
+            const int ncand = sv[SV_PP + 1], nS = sv[SV_PP + 2], nB = sv[SV_PP + 6];
+            const uint32_t nUc_all = (uint32_t) sv[SV_PP + 3];
+            const uint64_t U_l = (uint64_t)(uint32_t) sv[SV_PP + 4];
+            /* rho[k-1]'s digits into LDS (phase 4 uses the copy as well) */
+            if (BMs) { const dig_t *Mg = slip_piv_digits(P, M); for (int c = lane; c < lm; c += SLIP_WAVE) Ms[c] = slip_ld_u32(Mg + c); }
+            slip_wave_sync();                    /* the cursors and the digits are in LDS */
+            SLIP_TR(1);                          /* 1: the chain's one round of loads */
+            pc_col = sv[SV_TMP3];
+            const int64_t Lnz_ = sv64[SV_LNZ / 2], Lnl_ = sv64[SV_LNL / 2], Unz_ = sv64[SV_UNZ / 2], Unl_ = sv64[SV_UNL / 2];
+            /* the bounds with rho[k-1]'s share added; the same checks as the full pass makes */
+            const bool A_ok = lm + 2 <= P.xcap && lm + 2 <= 256;
+            const int nA = lm > 2 ? nS : 0;      /* one limb times a one-limb pivot stays in the lane, anything longer goes into the slab */
+            const int maxc = sv[SV_PP + 9] - SLIP_PP_BIAS + brho;
+            const int maxub_all = maxc > sv[SV_PP + 10] ? maxc : sv[SV_PP + 10];
+            const uint64_t L_b = (uint64_t)(uint32_t) sv[SV_PP + 5] + (uint64_t) nB * (uint64_t)((brho + 63) >> 6) + (lm <= 2 ? 2ull * (uint64_t) nS : 0ull);
+            const uint64_t preserve = (uint64_t)((maxub_all + 63) >> 6) + 1;
+            const uint64_t Lb_total = (uint64_t) nA * (uint64_t) slot + preserve + L_b;
+            const uint64_t Ub_total = U_l + preserve;
+            const int nLc = nrows - (int) nUc_all;
+            int ok = 1;
+            if (lm > 2 && !A_ok && nS > 0) ok = 0;
+            if (nB > 0) {
+                const int Wn = ((sv[SV_PP + 7] - SLIP_PP_BIAS + brho + 31) >> 5) + ((sv[SV_PP + 8] + 31) >> 5) + 1;
+                if (Wn > P.wcap || Wn > P.xcap || Wn > P.invcap || lm > P.wcap) ok = 0;
+            }
+            if (Lnz_ + nLc > P.Lcap_nz || Lnl_ + (int64_t) Lb_total > P.Lcap_nl) ok = 0;
+            if (Unz_ + (int) nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t) Ub_total > P.Ucap_nl) ok = 0;
+            if (P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) ok = 0;
+#ifdef SLIP_PROFILING
+            if (lane == 0) P.dbg[17 * (int64_t) P.n + k] |= 0x100 | (ok ? 0x200 : 0) | ((lm > 2 && !A_ok && nS > 0) ? 0x400 : 0)
+                | ((Lnz_ + nLc > P.Lcap_nz || Lnl_ + (int64_t) Lb_total > P.Lcap_nl) ? 0x800 : 0)
+                | ((Unz_ + (int) nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t) Ub_total > P.Ucap_nl) ? 0x1000 : 0)
+                | ((P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) ? 0x2000 : 0);
+#endif
+            const int diag_cand = (scheme == 1 || scheme == 3 || scheme == 4) && pc_col >= k && P.xrow[col].tag == tag && P.xrow[col].len != 0;
+            const int slotw = (lm + 5) & ~1;
+            const int nstage = (3 * SLIP_PAT_CAP) / slotw < 30 ? (3 * SLIP_PAT_CAP) / slotw : 30;
+            uint32_t *wlB = work, *wlA = work + 2 * SLIP_CAND_CAP;
+            int ncA = 0, ncB = 0;
+            if (ok) {
+                /* every lane brings its candidate to level k-1, or lists it for the wave: A -> 5-word record, B -> history item */
+                int wantA = 0, wantB = 0;
+                if (c_t >= 0) {
+                    const uint32_t inf = f_inf[c_t];
+                    const int cls = (int)(inf & 3u), ub = (int)(inf >> 2) - SLIP_PP_BIAS + brho;
+                    int done = 0;
+                    if (slip_abs(c_x.len) <= 2 && lm <= 2) {
+                        const uint64_t xv = cls == 2 ? ((uint64_t) f_k0[c_t] | ((uint64_t) f_k1[c_t] << 32)) : slip_limb0(P.xd + (int64_t) c_r * P.xcap);
+                        slip_u128 y = 0; int ys = 1;
+                        if (slip_history_small(P, c_x, xv, M, c_x.h, &y, &ys)) {
+                            slip_store_small(P, c_r, y, ys, k - 1, tag);
+                            const int yb = slip_bits128(y);
+                            const uint64_t top = yb ? (uint64_t)((y << (128 - yb)) >> 64) : 0ull;
+                            uint64_t key = ((uint64_t) yb << 40) | (top >> 24);
+                            if (kind == 1) key = ~key;
+                            f_k0[c_t] = (uint32_t) key; f_k1[c_t] = (uint32_t)(key >> 32);
+                            f_inf[c_t] = 1u | ((uint32_t) yb << 2);
+                            done = 1;
+                        }
+                    }
+                    if (!done) {
+                        if (cls == 2) wantA = 1; else wantB = 1;
+                        f_inf[c_t] = (uint32_t) cls | ((uint32_t)(ub > 1 ? ub : 1) << 2);
+                    }
+                    f_pos[c_t] = (uint32_t) c_pos;
+                }
+                const uint64_t mA = slip_ballot(wantA), mB = slip_ballot(wantB), below = (1ull << lane) - 1ull;
+                ncA = slip_popc64(mA); ncB = slip_popc64(mB);
+                if (wantA) {
+                    const int at = slip_popc64(mA & below);
+                    const uint32_t ax = f_aux[c_t];
+                    wlA[5 * at] = (uint32_t) c_r; wlA[5 * at + 1] = f_k0[c_t]; wlA[5 * at + 2] = f_k1[c_t];
+                    wlA[5 * at + 3] = ((uint32_t) c_t << 3) | ((ax >> 14) & 1u ? 4u : 0u) | ((ax >> 12) & 3u);
+                    wlA[5 * at + 4] = (ax & 0x3FFu) * (uint32_t) slot;
+                } else if (wantB) wlB[slip_popc64(mB & below)] = (uint32_t) c_r;
+                slip_wave_sync();
+                if (ncA > 0) {
+                    const SlipCandOut co = { f_k0, f_k1, f_inf, stage, slotw, nstage, kind };
+                    const int e = slip_mul_rows_any(P, M, BMs ? Ms : slip_piv_digits(P, M), BMs ? 0 : 1, wlA, 0, 1, ncA, Lnl_, (uint32_t *) 0, (uint32_t *) 0, tag, &co);
+                    if (e && lane == 0) sv[SV_ERR] = 1;
+                    if (ncA > nstage || diag_cand) slip_vm_drain();
+                }
+                for (int t = 0; t < ncB; t++) {
+                    const int e = slip_run_item_out(&P, 2, 0, 0, k, 0, wlB, t, b0, b1, b2);
+                    if (e && lane == 0) sv[SV_ERR] = e;
+                }
+                slip_wave_sync();
+                SLIP_TR(5);                      /* 5: the candidates' arithmetic */
+            }
+            if (ok && !sv[SV_ERR]) {
+                const CommitArgs ca = { ncand, diag_cand, nA, nLc, ncA + ncB, slotw, 1, nUc_all, U_l, Lb_total, Lnz_, Lnl_, Unz_, Unl_, ppcl };
+                search_publish(ca);
+            } else {
+                if (lane == 0) sv[SV_EST] = ok ? SLIPDEV_INTERNAL : -1;      /* the bounds said this could not happen / the full pass */
+                slip_block_sync_named(1);
+            }
+            if (lane == 0 && ok && !sv[SV_EST]) slip_agent_add_u64(&st->c_short, 1ull);
+#ifdef SLIP_PROFILING
+            if (lane == 0 && ok) { prof_[23] += 1; prof_[15] += (unsigned long long)(ncA + ncB); }
+#endif
+        } else {
+            /* the position snapshot (pinv as the reference has it at column k) by the other waves, before the swap */
+            for (int t = tid - SLIP_WAVE; t < nrows; t += T - SLIP_WAVE) {
+                const int r = (int) f_row[t];
+                const int pos = slip_ld_i32(&P.pinv[r]);
+                slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
+                f_pos[t] = (uint32_t) pos;
+            }
+            slip_block_sync_named(1);
+        }
+        slip_block_sync();                       /* the join: wave 0 has published (or given the column to the full pass) */
+        ec = sv[SV_EST];
+        pc_col = sv[SV_TMP3];
+        if (ec > 0) return ec;
+        if (ec == 0) { early = 1; e_pivrow = sv[SV_EPR]; e_pivpos = sv[SV_EPP]; }
+        SLIP_STAMP(6);
+    }
+    if (ec < 0) {
     /* class of a row for the early commit: 0 not a candidate (pivotal or zero), 1 exact (value at level k-1 in its x
      * row), 2 pending A (one limb times the long pivot -> straight into the L slab), 3 pending B (wave item) */
     uint64_t ulimbs = 0, lbound = 0; int nUc = 0, bad = 0, maxub = 0; uint32_t best_b = kind == 1 ? 0u : 0xFFFFFFFFu;
@@ -477,7 +1019,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         const int t = t0 + tid;
         int cls = 0, ub = 0, isA = 0, r = 0, pos = 0; uint32_t asgn = 0;
         if (t < nrows) {
-            if (t0 == 0) { r = r0_; pos = pos0_; }            /* loaded above, with everything else */
+            if (t0 == 0 && !fastc) { r = r0_; pos = pos0_; }  /* loaded above, with everything else */
             else {
                 r = small ? (int) f_row[t] : P.rlist[t];      /* short patterns: listed in LDS since their discovery */
                 pos = slip_ld_i32(&P.pinv[r]);
@@ -486,7 +1028,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             if (small) f_pos[t] = (uint32_t) pos; else P.rpos[t] = pos;
         }
         if (try_early && t < nrows) {
-            const SlipRow xr = t0 == 0 ? xr0_ : P.xrow[r];
+            const SlipRow xr = (t0 == 0 && !fastc) ? xr0_ : P.xrow[r];
             if (pos < k) { ulimbs += (uint64_t) slip_limbs(xr.len); nUc++; if (xr.bits > maxub) maxub = xr.bits; }
             else if (xr.len == 0) cls = 0;
             else if (xr.h >= k - 1) {
@@ -545,54 +1087,15 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         }
     }
     SLIP_TR(1);                                              /* 1: loads + classification */
-    /* rho[k-1]'s digits for the candidate multiplies: staged in LDS while the reduction below runs */
-    const bool BMs = SCR_LDS && lm <= wcap;
-    dig_t *Ms = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + nw * 3 * wcap : (dig_t *) 0;
     if (try_early && BMs) { const dig_t *Mg = slip_piv_digits(P, M); for (int c = tid; c < lm; c += T) Ms[c] = slip_ld_u32(Mg + c); }
     slip_block_sync();
     SLIP_TR(2);                                              /* 2: rho staging + barrier */
-    const int pc_col = sv[SV_TMP3];
+    pc_col = sv[SV_TMP3];
 #ifdef SLIP_PROFILING
-    const unsigned long long tr_t2_ = slip_clock();
-    const unsigned long long tr_sweep_ = t_last_ ? tr_t2_ - t_last_ : 0;      /* sweep tail + position snapshot */
+    tr_t2_ = slip_clock();
+    tr_sweep_ = t_last_ ? tr_t2_ - t_last_ : 0;              /* sweep tail + position snapshot */
 #endif
     SLIP_STAMP(2);
-
-    /* where the digits of a row are: its x row (private), or (rows multiplied straight into L: h == -2) the slab (shared) */
-    auto row_direct = [&](int r) -> int { return P.xrow[r].h == -2; };
-    auto row_digits = [&](int r) -> const dig_t * {
-        const dig_t *X = P.xd + (int64_t) r * P.xcap;
-        return P.xrow[r].h == -2 ? (const dig_t *)(P.Llimbs + *(const int64_t *) X) : X;
-    };
-    /* the tolerance test of the diagonal preference between the best candidate `pr` and the diagonal row `col`
-     * (slip_get_pivot.c:89-118, 126-146): 1 = take the diagonal; *err: scratch too small */
-    auto diag_rule = [&](int pr, int *err) -> int {
-        if (scheme == 1 || P.tol_mode == 0) return 1;
-        const int lp_ = slip_abs(P.xrow[pr].len), lc_ = slip_abs(P.xrow[col].len);
-        /* tol_m has exactly 53 bits, so tol_m*|den| has 52 or 53 bits more than |den|: most columns
-         * are decided by the bit lengths alone */
-        const int te0 = P.tol_e;
-        const int bnum_ = (scheme == 3 ? P.xrow[pr].bits : P.xrow[col].bits) + (te0 < 0 ? -te0 : 0);
-        const int bden_ = (scheme == 3 ? P.xrow[col].bits : P.xrow[pr].bits) + (te0 > 0 ? te0 : 0);
-        if (bnum_ < 52 + bden_) return 0;
-        if (bnum_ > 53 + bden_) return 1;
-        /* exact comparison.  Every wave runs it redundantly in its own scratch.  A row that lives in the L
-         * slab is shared data: its digits are staged (sc1 loads) into scratch the comparison does not need
-         * at that point -- the denominator into b1 (free until the last step, when the denominator has
-         * been consumed), the numerator behind the product in b2. */
-        const int rn = scheme == 3 ? pr : col, rd = scheme == 3 ? col : pr;   /* |small|/|diag| or |diag|/|large| >= tol */
-        const int ln = scheme == 3 ? lp_ : lc_, ldn = scheme == 3 ? lc_ : lp_;
-        const dig_t *num = P.xd + (int64_t) rn * P.xcap, *den = P.xd + (int64_t) rd * P.xcap;
-        if (ldn + 2 > wcap) { *err = 1; return 0; }
-        if (row_direct(rd)) { slip_stage_shared(b1, row_digits(rd), ldn); den = b1; }
-        if (row_direct(rn)) {
-            if (ldn + 4 + ln > wcap) { *err = 1; return 0; }
-            slip_stage_shared(b2 + ldn + 4, row_digits(rn), ln); num = b2 + ldn + 4;
-        }
-        const int tk = slip_tol_compare_out(P.tol_m, P.tol_e, num, ln, den, ldn, b0, b1, b2, wcap);
-        if (tk < 0) { *err = 1; return 0; }
-        return tk;
-    };
 
     /* ---- early commit: choose and publish the pivot BEFORE the column's bulk arithmetic.
      * The final values are x * rho[k-1] / rho[h]; their bit lengths are known to within two bits from the operands'
@@ -601,8 +1104,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
      * (stage 1) and the frontier moves; every other row is multiplied / divided afterwards, off the commit chain.
      * The column must be certain to complete: capacities, widths and the column-window cap are checked on the bounds
      * first, otherwise the column takes the complete path below (everything computed, then the search, then the commit). */
-    int early = 0, e_pivrow = -1, e_pivpos = -1;
-    if (try_early) {
+    /* returns 0: committed (outcome in sv[SV_EPR], sv[SV_EPP]); -1: take the complete path; > 0: a status.  Run by every
+     * thread, or (single-wave chain) by wave 0 alone */
+    auto early_commit = [&]() -> int {
         /* one fused reduction: sums (U limbs, L limb bound, pivotal rows), maxima (trouble flag, longest bound), best bound.
          * Inside a wave with DPP row shifts (limb counts of a column stay far below 2^32), across the waves through LDS. */
         {
@@ -639,12 +1143,16 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         if (Lnz_ + nLc > P.Lcap_nz || Lnl_ + (int64_t) Lb_total > P.Lcap_nl) ok = 0;
         if (Unz_ + (int) nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t) Ub_total > P.Ucap_nl) ok = 0;
         if (P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) ok = 0;  /* the window may end here: decide on exact values */
+#ifdef SLIP_PROFILING
+        if (tid == 0) P.dbg[17 * (int64_t) P.n + k] |= 0x4000 | (ok ? 0x8000 : 0) | (bad_all ? 0x400 : 0)
+            | ((Lnz_ + nLc > P.Lcap_nz || Lnl_ + (int64_t) Lb_total > P.Lcap_nl) ? 0x800 : 0)
+            | ((Unz_ + (int) nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t) Ub_total > P.Ucap_nl) ? 0x1000 : 0)
+            | ((P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) ? 0x2000 : 0);
+#endif
         const int diag_cand = (scheme == 1 || scheme == 3 || scheme == 4) && pc_col >= k && P.xrow[col].tag == tag && P.xrow[col].len != 0;
         /* lists in the work area: class-B candidates (rows), all candidates (table indices), class-A candidates (5-word records) */
         uint32_t *wlB = work, *cl = work + SLIP_CAND_CAP, *wlA = work + 2 * SLIP_CAND_CAP;
         volatile int32_t *cntA = &sv[SV_CNT0 + 1], *cntB = &sv[SV_CNT0 + 2], *cntC = &sv[SV_LISTN];
-        /* a candidate's product is also left in LDS (slots over the areas phase 3c fills later) for the publishing wave */
-        dig_t *stage = lds + SLIP_LDS_PAT;
         const int slotw = (lm + 5) & ~1;                      /* even: the low limb is read as one aligned 64-bit word */
         const int nstage = (3 * SLIP_PAT_CAP) / slotw < 30 ? (3 * SLIP_PAT_CAP) / slotw : 30;   /* the slot number travels in 5 bits of f_inf */
         if (ok) {
@@ -704,139 +1212,24 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             if (sv[SV_ERR]) return SLIPDEV_INTERNAL;          /* the bounds said this could not happen */
             SLIP_STAMP(22);                                   /* early: candidate lists and arithmetic */
             SLIP_TR(5);                                       /* 5: candidate multiplies + barrier */
-            /* the exact search among the candidates (all exact now), slip_get_pivot.c:58-155: (bit length, leading bits)
-             * keys; the candidates that tie on the best key are compared exactly, then by position.  Every wave does the
-             * whole (short) search by itself: lanes = candidates, no workgroup barrier. */
-            auto key_of = [&](int t) -> uint64_t {
-                if (kind == 2) return (uint64_t) f_pos[t];
-                const int cls = (int)(f_inf[t] & 3u);
-                uint64_t key = (uint64_t) f_k0[t] | ((uint64_t) f_k1[t] << 32);
-                if (cls == 3 || (cls == 1 && key == ~0ull)) {          /* value produced by a wave item / final before: key from its digits */
-                    const int r = (int) f_row[t];
-                    const SlipRow xr = P.xrow[r];
-                    const uint64_t top = slip_top64(row_digits(r), slip_abs(xr.len), xr.h == -2);
-                    key = ((uint64_t) xr.bits << 40) | (top >> 24);
-                    if (kind == 1) key = ~key;
-                }
-                return key;
-            };
-            /* ONE wave searches and publishes (the publishing wave rewrites the pivot row's state: nobody else may be
-             * looking at it); the others wait at the barrier below and read the outcome there */
             if (wave == 0) {
-            int est = 0;
-            uint64_t mk = ~0ull;
-            for (int c0 = 0; c0 < ncand; c0 += SLIP_WAVE) {
-                const int c = c0 + lane;
-                const uint64_t key = c < ncand ? key_of((int) cl[c]) : ~0ull;
-                /* 64-bit minimum over the wave: the high words first, the low words among the lanes that hold the minimum */
-                const uint32_t mh = slip_wave_min_u32((uint32_t)(key >> 32));
-                const uint32_t ml = slip_wave_min_u32((uint32_t)(key >> 32) == mh ? (uint32_t) key : 0xFFFFFFFFu);
-                const uint64_t wm = ((uint64_t) mh << 32) | ml;
-                if (wm < mk) mk = wm;
+                const CommitArgs ca = { ncand, diag_cand, nA, nLc, ncA + ncB, slotw, 0, nUc_all, U_l, Lb_total, Lnz_, Lnl_, Unz_, Unl_, cl };
+                search_publish(ca);
             }
-            int bt = -1;
-            const int kbits = kind == 2 ? 0 : (int)((kind == 0 ? mk : ~mk) >> 40);
-            for (int c0 = 0; c0 < ncand; c0 += SLIP_WAVE) {
-                const int c = c0 + lane;
-                const int t = c < ncand ? (int) cl[c] : -1;
-                uint64_t tie = slip_ballot(t >= 0 && key_of(t) == mk);
-                while (tie) {
-                    const int l = slip_ctz64(tie); tie &= tie - 1;
-                    const int tt = (int) slip_readlane((uint32_t) t, l);
-                    if (bt < 0) { bt = tt; continue; }
-                    const int rb = (int) f_row[bt], rt = (int) f_row[tt];
-                    int cmp = 0;
-                    if (kbits > 40)      /* at most 40 bits: equal keys are equal values */
-                        cmp = slip_cmp_mag(row_digits(rb), row_direct(rb), row_digits(rt), row_direct(rt), slip_abs(P.xrow[rt].len));
-                    if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && f_pos[tt] < f_pos[bt])) bt = tt;
-                }
-            }
-            if (bt < 0) { est = SLIPDEV_INTERNAL; bt = 0; }
-            e_pivrow = (int) f_row[bt]; e_pivpos = (int) f_pos[bt];
-            int stg = (int)((f_inf[bt] >> 26) & 31u) - 1;     /* LDS slot of the pivot's digits, or -1 */
-            /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); col's value is exact: it was a candidate */
-            if (!est && diag_cand && e_pivrow != col) {
-                int derr = 0;
-                const int take = diag_rule(e_pivrow, &derr);
-                if (derr) est = SLIPDEV_GROW_X;
-                else if (take) { e_pivrow = col; e_pivpos = pc_col; stg = -1; }
-            }
-            SLIP_STAMP(13);
-            if (est) { if (lane == 0) sv[SV_EST] = est; }
-            else {
-            SLIP_TR(6);                                       /* 6: search + diag */
-            /* stage 1, early: the pivot's digits written through to the L slab (its class-A slot, or the reserved slot behind
-             * those), the pivot record, the permutation swap, the column pointers (limb offsets from the bounds), ONE
-             * drain, the frontier */
-            SlipRow pxr; int pdirect; int64_t poff;
-            if (stg >= 0) {
-                /* a class-A candidate multiplied a moment ago: everything about it is in LDS */
-                uint64_t key = (uint64_t) f_k0[bt] | ((uint64_t) f_k1[bt] << 32);
-                if (kind == 1) key = ~key;
-                pxr.bits = (int)(key >> 40);
-                const int len_ = (pxr.bits + 31) >> 5;
-                pxr.len = (f_inf[bt] >> 31) ? -len_ : len_; pxr.h = -2; pxr.tag = tag;
-                pdirect = 1; poff = Lnl_ + (int64_t)(f_aux[bt] & 0x3FFu) * slot;
-            } else {
-                pxr = P.xrow[e_pivrow];
-                pdirect = pxr.h == -2;
-                poff = pdirect ? *(const int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) : Lnl_ + (int64_t) nA * slot;
-            }
-            const uint64_t plimbs = (uint64_t) slip_limbs(pxr.len);
-            {
-                const int lp_ = slip_abs(pxr.len);
-                dig_t *dst = (dig_t *)(P.Llimbs + poff);
-                /* where the digits are: the LDS slot the multiplying wave left, the slab (a class-A row that was not staged:
-                 * its stores were drained above), or the row's private x */
-                const dig_t *src = stg >= 0 ? (const dig_t *)(stage + stg * slotw) : (pdirect ? (const dig_t *) dst : P.xd + (int64_t) e_pivrow * P.xcap);
-                const int z = slip_publish_digits(dst, src, stg < 0 && pdirect, lp_);
-                const uint64_t lo64 = (stg < 0 && pdirect) ? slip_ld_u64((const uint64_t *) dst) : *(const uint64_t *) src;
-                if (lane == 0) {
-                    SlipPiv pr; pr.off = poff; pr.len = pxr.len; pr.bits = pxr.bits; pr.ctz = z; pr.invlen = 0;
-                    pr.lo = lo64; pr.inv64 = 0; pr.pad = 0;
-                    if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
-                    slip_st_piv(&P.piv[k], pr);
-                    const int intermed = e_pivpos, intermed2 = sv[SV_TMP];
-                    slip_st_i32(&P.row_perm[k], e_pivrow); slip_st_i32(&P.row_perm[intermed], intermed2);
-                    slip_st_i32(&P.pinv[e_pivrow], k); slip_st_i32(&P.pinv[intermed2], intermed);
-                    slip_st_i64(&P.Up[k + 1], Unz_ + (int) nUc_all + 1); slip_st_i64(&P.Lp[k + 1], Lnz_ + nLc);
-                    slip_st_i64(&P.Uo[k + 1], Unl_ + (int64_t)(U_l + plimbs)); slip_st_i64(&P.Lo[k + 1], Lnl_ + (int64_t) Lb_total);
-                }
-                SLIP_TR(7);                                       /* 7: publish stores issued */
-                slip_vm_drain();                                  /* the digits (all lanes) and the records (lane 0) have left */
-                if (lane == 0) {
-                    slip_st_frontier(st, k + 1, e_pivrow);
-#ifdef SLIP_PROFILING
-                    if (t_last_) prof_[18] += slip_clock() - t_last_;
-                    {
-                        int32_t *tr = P.dbg + 8 * (int64_t) k; const unsigned long long nowc = slip_clock();
-                        tr[0] = t_last_ ? (int32_t)(nowc - t_last_) : -1; tr[1] = 1; tr[2] = ncA + ncB; tr[3] = nrows;
-                        tr[4] = (int32_t) tr_sweep_; tr[5] = (int32_t)(nowc - tr_t2_); tr[7] = P.worker;
-                        tr[6] = (int32_t) slip_realtime(); P.dbg[8 * (int64_t) P.n + k] = (int32_t) t_wait_[2];
-                        for (int q_ = 0; q_ < 8; q_++) P.dbg[9 * (int64_t) P.n + 8 * (int64_t) k + q_] = trs_[q_];
-                        P.dbg[9 * (int64_t) P.n + 8 * (int64_t) k + 7] = (int32_t)(nowc - trp_) + trs_[7] * 0;     /* 7b: drain */
-                    }
-#endif
-                    /* from now on the pivot row lives in the slab like a class-A row */
-                    if (!pdirect) {
-                        SlipRow nr = pxr; nr.h = -2; P.xrow[e_pivrow] = nr;
-                        *(int64_t *)(P.xd + (int64_t) e_pivrow * P.xcap) = poff;
-                    }
-                    sv64[SV_LALLOC / 2] = (int64_t)((uint64_t) nA * (uint64_t) slot + (pdirect ? 0ull : plimbs));
-                    sv[SV_EPR] = e_pivrow; sv[SV_EPP] = e_pivpos; sv[SV_EST] = 0;
-                }
-            }
-            }       /* !est */
-            }       /* wave 0 */
-            slip_block_sync();
-            if (sv[SV_EST]) return sv[SV_EST];
-            e_pivrow = sv[SV_EPR]; e_pivpos = sv[SV_EPP];
-            early = 1;
-            SLIP_STAMP(6);
 #ifdef SLIP_PROFILING
             if (tid == 0) { prof_[23] += 1; prof_[15] += (unsigned long long)(ncA + ncB); }   /* early commits; their candidates that needed arithmetic */
 #endif
+            slip_block_sync();
+            return sv[SV_EST];
         }
+        return -1;
+    };
+    if (try_early) {
+        ec = early_commit();
+        if (ec > 0) return ec;
+        if (ec == 0) { early = 1; e_pivrow = sv[SV_EPR]; e_pivpos = sv[SV_EPP]; }
+        SLIP_STAMP(6);
+    }
     }
     /* ---- phase 3c: reading the bitmap in order = the sorted pattern (slip_sort_xi.c); every row goes to the place of
      *      its snapshot position (binary search over the sorted positions) ---- */
@@ -1204,6 +1597,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             const int intermed = pivpos, intermed2 = slip_ld_i32(&P.row_perm[k]);
             slip_st_i32(&P.row_perm[k], pivrow); slip_st_i32(&P.row_perm[intermed], intermed2);
             slip_st_i32(&P.pinv[pivrow], k); slip_st_i32(&P.pinv[intermed2], intermed);
+            slip_st_i32(&P.sw_row[k], intermed2); slip_st_i32(&P.sw_pos[k], intermed);
             slip_st_i64(&P.Up[k + 1], Unz + nUe); slip_st_i64(&P.Lp[k + 1], Lnz + nL);
             slip_st_i64(&P.Uo[k + 1], Unl + (int64_t) totU); slip_st_i64(&P.Lo[k + 1], Lnl + (int64_t) totL);
             slip_vm_drain();
@@ -1286,6 +1680,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         slip_agent_max_u64(&st->c_maxdig, (unsigned long long) maxdig);
     }
     acc[0] += c_read; acc[1] += c_upd; acc[2] += c_src; acc[3] += c_str; acc[4] += c_mac;
+#ifdef SLIP_PROFILING
+    if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 4] = (int32_t) slip_realtime();          /* time line 4: the column ends */
+    if (tid == 0) P.dbg[17 * (int64_t) P.n + k] |= (packaged ? 1 : 0) | (adopted ? 2 : 0) | (fastc ? 4 : 0) | (early ? 8 : 0) | (sv[SV_PKGVER] << 4) | (nrows << 16);
+#endif
     SLIP_STAMP(7);
     SLIP_STAMP_FLUSH(st);
     slip_block_sync();

@@ -181,7 +181,8 @@ slip_factor_kernel(SlipParams P, SlipState *st)
     __shared__ SlipParams sP;
     if (threadIdx.x == 0) slip_worker_params(&sP, P, (int) blockIdx.x);
     __syncthreads();
-    slip_factor_worker<FAST>(sP, st, slip_lds);
+    if (sP.committer && blockIdx.x == 0) slip_committer<FAST>(sP, st, slip_lds);
+    else slip_factor_worker<FAST>(sP, st, slip_lds);
     slip_worker_exit(sP, st);
 }
 
@@ -255,6 +256,7 @@ struct slip_hip_factor {
     int32_t n; int64_t annz, alimbs;
     int32_t waves, lds_words, bitmap_in_lds, scratch_in_lds;
     int32_t nworkers;      /* column workers = workgroups of a launch; private arrays are sized for this many */
+    int32_t no_committer;  /* diagnostics: every column is committed by its own worker */
     int32_t last_status, window_end, launches;
     int32_t factors_only;  /* built from given factors (slip_hip_factor_from_factors): solve only, no A */
     double kernel_ms, solve_ms;
@@ -389,6 +391,11 @@ static int alloc_x(slip_hip_factor *f, int32_t xcap, int keep_rows)
     if (dev_alloc(&P->invd, n * (int64_t) P->invcap)) return SLIP_HIP_OUT_OF_MEMORY;
     if (dev_alloc(&P->gscratch, f->scratch_in_lds ? 1 : W * SLIP_SCRATCH_WAVES * 3 * (int64_t) P->wcap)) return SLIP_HIP_OUT_OF_MEMORY;
     if (dev_alloc(&P->gbitmap, f->bitmap_in_lds ? 1 : W * ((int64_t) P->bm_words + 64))) return SLIP_HIP_OUT_OF_MEMORY;
+    if (!keep_rows || !P->pkg) {
+        if (P->pkg) hipFree(P->pkg);
+        P->pkg = NULL;
+        if (dev_alloc(&P->pkg, W * (int64_t) SLIP_PKG_WORDS)) return SLIP_HIP_OUT_OF_MEMORY;
+    }
     return 0;
 }
 
@@ -430,7 +437,7 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
     hipFree(P->piv); hipFree(P->invd);
     hipFree(P->Lp); hipFree(P->Lo); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
     hipFree(P->Up); hipFree(P->Uo); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
-    hipFree(P->Lready); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg);
+    hipFree(P->Lready); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg); hipFree(P->pkg); hipFree(P->sw_row); hipFree(P->sw_pos);
     hipFree(f->ds); hipFree(f->ident);
     rescale_drop(f);
     if (f->ev0) hipEventDestroy(f->ev0);
@@ -445,6 +452,7 @@ static void apply_options(slip_hip_factor *f, const slip_hip_options &opt)
     if (f->waves > SLIP_MAX_WAVES) f->waves = SLIP_MAX_WAVES;
     f->nworkers = opt.workers > 0 ? opt.workers : 0;      /* 0: chosen in alloc_x once the LDS need is known */
     f->P.no_early = opt.reserved & 1;
+    f->no_committer = (opt.reserved >> 1) & 1;
     if (f->nworkers > 4096) f->nworkers = 4096;
 }
 
@@ -542,16 +550,17 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     A_(dev_alloc(&f->dAp, (int64_t) n + 1)); A_(dev_alloc(&f->dAi, onz)); A_(dev_alloc(&f->dAlen, onz));
     A_(dev_alloc(&f->dAoff, onz)); A_(dev_alloc(&f->dAlimbs, ol)); A_(dev_alloc(&f->dq, n));
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 20 * (int64_t) n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n)); A_(dev_alloc(&P->sw_row, n)); A_(dev_alloc(&P->sw_pos, n));
     A_(make_ident(f));
-    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 20 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 24 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc && hipMemset(P->piv, 0, (size_t) n * sizeof(SlipPiv)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     /* initial sizes: S->lnz/unz only size the first allocation in the reference too */
     P->Lcap_nz = opt.lnz_hint > 0 ? opt.lnz_hint : 4 * onz + n;
     P->Ucap_nz = opt.unz_hint > 0 ? opt.unz_hint : 4 * onz + n;
     if (P->Lcap_nz < n) P->Lcap_nz += n;
     if (P->Ucap_nz < n) P->Ucap_nz += n;
-    const int32_t cap_digits = opt.limb_cap > 0 ? 2 * opt.limb_cap + 8 : 0;
+    /* window mode: the cap, plus room for the working width of a division item on a value at the cap (result + shifted-out zeros of rho[h] + 1) */
+    const int32_t cap_digits = opt.limb_cap > 0 ? 2 * opt.limb_cap + 40 : 0;
     int32_t xcap0 = cap_digits > 0 ? cap_digits : (2 * maxdig + 8 > 16 ? 2 * maxdig + 8 : 16);
     P->Lcap_nl = P->Lcap_nz * 2;
     P->Ucap_nl = P->Ucap_nz * 2;
@@ -616,9 +625,13 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
     { const int e = upload_state(f, stream); if (e) return e; }
     /* no more workers than columns left */
     int32_t W = f->nworkers;
-    if (W > f->P.k_stop - f->hs.F) W = f->P.k_stop - f->hs.F;
+    /* block 0 of a launch with at least two workgroups of at least two waves is the committer (ref_lu_pipe_commit.h) */
+    f->P.committer = W >= 2 && f->waves >= 2 && f->bitmap_in_lds && f->scratch_in_lds && !f->P.no_early && !f->no_committer && f->P.pivot_scheme != 2 && f->P.pkg != NULL;
+    if (W > f->P.k_stop - f->hs.F + f->P.committer) W = f->P.k_stop - f->hs.F + f->P.committer;
     if (W < 1) W = 1;
+    if (W < 2) f->P.committer = 0;
     f->P.nworkers = W;
+    if (f->P.committer) CK(hipMemsetAsync(f->P.pkg, 0, (size_t) W * SLIP_PKG_WORDS * 4, stream));
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;
@@ -642,7 +655,8 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
             SlipParams Pw;
             slip_worker_params(&Pw, P, slip_block());
             uint32_t *lds = lds_all + (size_t) slip_block() * words;
-            if (fast) slip_factor_worker<true>(Pw, ds, lds);
+            if (Pw.committer && slip_block() == 0) { if (fast) slip_committer<true>(Pw, ds, lds); else slip_committer<false>(Pw, ds, lds); }
+            else if (fast) slip_factor_worker<true>(Pw, ds, lds);
             else slip_factor_worker<false>(Pw, ds, lds);
             slip_worker_exit(Pw, ds);
         });
@@ -781,11 +795,11 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     int rc = 0;
 #define A_(call) do { if (!rc) rc = (call); } while (0)
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 20 * (int64_t) n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n)); A_(dev_alloc(&P->sw_row, n)); A_(dev_alloc(&P->sw_pos, n));
     A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Lo, (int64_t) n + 1)); A_(dev_alloc(&P->Li, lnz)); A_(dev_alloc(&P->Le, lnz)); A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
     A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Uo, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, unz)); A_(dev_alloc(&P->Ue, unz)); A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
     A_(dev_alloc(&f->ds, 1));
-    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 20 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 24 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc) rc = alloc_x(f, 2 * maxdig + 8, 0);
 #undef A_
 #define UP_(dst, src, bytes) do { if (!rc && (bytes) > 0 && hipMemcpy((void *)(dst), (src), (size_t)(bytes), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR; } while (0)
@@ -1100,6 +1114,8 @@ extern "C" int slip_hip_factor_column_trace(const slip_hip_factor *f, int32_t *o
     CK(hipMemcpy(out + 8 * (int64_t) ncols, f->P.dbg + 8 * (int64_t) f->n, (size_t) ncols * 4, hipMemcpyDeviceToHost));
     /* words 9..16: cycles of the sub-steps of the commit chain */
     CK(hipMemcpy(out + 9 * (int64_t) ncols, f->P.dbg + 9 * (int64_t) f->n, (size_t) ncols * 8 * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(out + 17 * (int64_t) ncols, f->P.dbg + 17 * (int64_t) f->n, (size_t) ncols * 4, hipMemcpyDeviceToHost));      /* path flags */
+    CK(hipMemcpy(out + 18 * (int64_t) ncols, f->P.dbg + 18 * (int64_t) f->n, (size_t) ncols * 6 * 4, hipMemcpyDeviceToHost));  /* wall-clock time line, 6 words per column */
     return SLIP_HIP_OK;
 }
 
@@ -1114,6 +1130,7 @@ extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)
     o->max_limbs = (int64_t)((h->c_maxdig + 1) / 2);
     o->kernel_ms = f->kernel_ms; o->launches = f->launches; o->xcap_digits = f->P.xcap;
     o->limb_macs = (int64_t) h->c_macs; o->workers = f->nworkers; o->waves = f->waves; o->lds_bytes = f->lds_words * 4;
+    o->short_commits = (int32_t)(uint32_t) h->c_short; o->committer_commits = (int32_t)(h->c_short >> 32);
     return SLIP_HIP_OK;
 }
 

@@ -31,7 +31,9 @@ static inline int slip_uniform_i32(int v) { return v; }
 static inline int slip_nblocks(void)  { return emu::nblocks(); }
 /* macros, so that the divergence check sees the CALL SITE's line */
 #define slip_block_sync()      emu::block_sync(__LINE__)
+#define slip_block_sync_named(id) emu::block_sync(-(id))     /* one barrier written at several places of the source */
 #define slip_wave_sync()       ((void) emu::ballot(0, __LINE__))
+#define slip_wave_sync_lds()   ((void) emu::ballot(0, __LINE__))
 #define slip_ballot(pred)      emu::ballot((pred), __LINE__)
 #define slip_shfl_u32(v, src)  ((uint32_t) emu::shfl((uint64_t)(v), (src), __LINE__))
 #define slip_shfl_u64(v, src)  emu::shfl((uint64_t)(v), (src), __LINE__)
@@ -60,6 +62,7 @@ static inline void slip_mac96(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t 
 }
 static inline uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 static inline int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v > o) *p = v; return o; }
+static inline int32_t  slip_atomic_min_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v < o) *p = v; return o; }
 static inline int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
 static inline unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline void slip_fence_block(void) {}
@@ -115,12 +118,23 @@ SLIP_DEV int slip_block(void)    { return (int) blockIdx.x; }
 SLIP_DEV int slip_uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }   /* v is the same in every lane */
 SLIP_DEV int slip_nblocks(void)  { return (int) gridDim.x; }
 SLIP_DEV void slip_block_sync(void) { __syncthreads(); }
+/* one barrier that different waves reach at different places of the source (the emulator checks that all threads of a
+ * workgroup meet at the same barrier: these are matched by name instead of by line) */
+SLIP_DEV void slip_block_sync_named(int) { __syncthreads(); }
 /* orders this wave's LDS/global writes before its lanes' later cross-lane reads */
 SLIP_DEV void slip_wave_sync(void)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+/* the same for LDS only: a wave's LDS operations execute in order, so only the compiler has to be told (no wait for
+ * outstanding global stores, which the workgroup-scope fences above imply) */
+SLIP_DEV void slip_wave_sync_lds(void)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 SLIP_DEV uint64_t slip_ballot(int pred) { return (uint64_t) __ballot(pred); }
 SLIP_DEV uint32_t slip_shfl_u32(uint32_t v, int src) { return (uint32_t) __shfl((int) v, src, SLIP_WAVE); }
@@ -187,6 +201,7 @@ SLIP_DEV void slip_mac96(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t b)
 }
 SLIP_DEV uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 SLIP_DEV int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { return atomicMax(p, v); }
+SLIP_DEV int32_t  slip_atomic_min_i32(int32_t *p, int32_t v) { return atomicMin(p, v); }
 SLIP_DEV int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { return atomicAdd(p, v); }
 SLIP_DEV unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 SLIP_DEV void slip_fence_block(void) { __threadfence_block(); }

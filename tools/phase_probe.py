@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_case
 import slip_lu_amd as sl
-path = os.path.join(ROOT, "slip_lu_amd", "csrc", "libslip_hip_prof.so")
+path = os.environ.get("SLIP_PROF_LIB") or os.path.join(ROOT, "slip_lu_amd", "csrc", "libslip_hip_prof.so")
 SLOTS = {0: "scatter", 1: "sweep(work)", 16: "wait F", 17: "wait F2", 20: "  sweep after last F wait", 2: "position snapshot",
          21: "early: classify", 22: "early: reduce+candidates", 13: "early: search+diag (or full search)", 6: "stage1 publish",
          14: "pattern+rank", 8: "hist:stage rho", 9: "hist:classify", 10: "hist:mul+drain",
@@ -18,7 +18,7 @@ waves = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 for name in sys.argv[1].split(","):
     entry, fix = load_case(name)
     f = sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], pivot=entry["pivot"],
-                         tol=entry["tol"], limb_cap=entry["cap"], lib_path=path, workers=workers, waves=waves)
+                         tol=entry["tol"], limb_cap=entry["cap"], lib_path=path, workers=workers, waves=waves, debug_flags=int(os.environ.get("SLIP_FLAGS", "0")))
     f.run(entry["kmax"], check=False); f.reset(); f.run(entry["kmax"], check=False)
     i = f.info()
     out = (C.c_ulonglong * 24)()
@@ -30,11 +30,16 @@ for name in sys.argv[1].split(","):
         print(f"    {label:36s} {out[slot] / K:12.2f}")
     if hasattr(f.lib, "slip_hip_factor_column_trace"):
         import numpy as np
-        tr = np.zeros(17 * i["K"], np.int32)
+        tr = np.zeros(24 * i["K"], np.int32)
         f.lib.slip_hip_factor_column_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         if f.lib.slip_hip_factor_column_trace(f.h, tr.ctypes.data, i["K"]) == 0:
             seen = tr[8 * i["K"]:9 * i["K"]].astype(np.int64)
-            sub = tr[9 * i["K"]:].reshape(-1, 8)
+            flags = tr[17 * i["K"]:18 * i["K"]]
+            tl = tr[18 * i["K"]:24 * i["K"]].reshape(-1, 6).astype(np.int64)
+            if os.environ.get("SLIP_TIMELINE"):
+                t0 = tl[:, 0].min()
+                np.save(os.environ["SLIP_TIMELINE"], np.concatenate([tl - t0, flags.reshape(-1, 1).astype(np.int64)], axis=1))
+            sub = tr[9 * i["K"]:17 * i["K"]].reshape(-1, 8)
             names = ["sweep tail", "loads+classify", "rho staging+barrier", "reduce+barrier", "marking+barrier", "cand multiply+barrier", "search", "publish issue (7b: then drain)"]
             good = sub[:, 1] > 0
             print("    chain sub-steps, median cycles: " + ", ".join(f"{n} {int(np.median(sub[good, q]))}" for q, n in enumerate(names)))
@@ -50,7 +55,7 @@ for name in sys.argv[1].split(","):
             worst = np.argsort(-c)[:12]
             for kcol in worst:
                 print(f"      col {kcol}: chain {tr[kcol, 0]} early {tr[kcol, 1]} cand {tr[kcol, 2]} rows {tr[kcol, 3]} "
-                      f"sweep-tail+snapshot {tr[kcol, 4]} pass+publish {tr[kcol, 5]} worker {tr[kcol, 7]}")
+                      f"sweep-tail+snapshot {tr[kcol, 4]} pass+publish {tr[kcol, 5]} worker {tr[kcol, 7]} path {int(flags[kcol]) & 0xFFFF:#x}")
             e = tr[:, 1] == 1
             if e.any():
                 print(f"    early columns: sweep-tail+snapshot mean {tr[e, 4].mean():.0f}, pass+publish mean {tr[e, 5].mean():.0f} "
