@@ -49,7 +49,7 @@ typedef struct slip_hip_options {
     int64_t unz_hint;     /*   cf. SLIP_LU_analysis.lnz/.unz; both grow on demand      */
     int32_t workers;      /* column workers (workgroups of a launch; each owns a private */
                           /*   dense vector): 0 = as many as can be resident            */
-    int32_t reserved;     /* diagnostics: bit 0 = no early commit, bit 1 = no committer workgroup */
+    int32_t reserved;     /* diagnostics: bit 0 = no early commit, bit 1 = no committer workgroup, bit 2 = no helping with long update queues */
 } slip_hip_options;
 
 typedef struct slip_hip_info {
@@ -68,7 +68,8 @@ typedef struct slip_hip_info {
     int32_t workers, waves;   /* launch shape: column workers x wavefronts each          */
     int32_t lds_bytes;        /* dynamic LDS per worker                                   */
     int32_t short_commits;    /* columns whose pivot was published by the short commit chain (diagnostic) */
-    int32_t committer_commits, pad2;   /* ... of those, by the committer workgroup */
+    int32_t committer_commits;         /* ... of those, by the committer workgroup */
+    int32_t farm_jobs, farm_items, pad2;   /* update queues opened to helpers; items helpers ran (diagnostic) */
 } slip_hip_info;
 
 typedef struct slip_hip_factor slip_hip_factor;

@@ -78,11 +78,12 @@ typedef struct SlipState {
     int32_t F2; int32_t padF2[31];                  /* ready frontier: columns < F2 have published their L entries (stage 2) */
     int32_t ticket; int32_t padT[31];               /* next column ticket (monotonic across launches)                    */
     int32_t exited, padE[31];                       /* workers that have left the launch (the last one writes the summary) */
+    int32_t farm_hint, padH[31];                    /* worker + 1 of a worker whose update queue is open to helpers (last writer wins; a hint) */
     int32_t k_next, status, status_k, solve_next;
     int64_t Lnz, Lnl, Unz, Unl;                     /* mirrors of Lp/Lo/Up/Uo at the frontier (written at kernel end)     */
     int64_t Lnl_exact, Unl_exact;                   /* limbs actually stored                                             */
     int64_t out_used;                               /* solve: limbs of the output slab in use                            */
-    unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig, c_macs, c_short;    /* c_short: columns committed by the short chain */
+    unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig, c_macs, c_short, c_farm;   /* c_farm: queues opened to helpers (low word), items helpers ran (high word) */    /* c_short: columns committed by the short chain */
     unsigned long long prof[24];                    /* -DSLIP_PROFILE_PHASES builds only */
 } SlipState;
 
@@ -110,6 +111,7 @@ typedef struct SlipParams {
     int32_t no_early;                               /* diagnostics: 1 = every column takes the complete path (no early commit) */
     int32_t committer;                              /* 1: block 0 of the launch is the committer (ref_lu_pipe_commit.h), the others are column workers */
     uint32_t *pkg;                                  /* shared: one package slot per worker (SLIP_PKG_WORDS words each)      */
+    uint32_t *jobs; int32_t farm, pad_f; SlipState *st;            /* shared: one job slot per worker (SLIP_JOB_WORDS words): a long update queue other workers help with */
     int32_t *sw_row, *sw_pos;                       /* shared: the swap log -- column c's pivot changed places with row sw_row[c] (= row_perm[c] before), which moved to position sw_pos[c] (= the pivot row's position before) */
     int64_t priv_rows;                              /* rows per worker of the private arrays (= n)                      */
     int32_t *dbg;
@@ -166,13 +168,14 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
 /* a column's package for the committer (ref_lu_pipe_commit.h), offsets in 32-bit words */
 #define SLIP_PKG_CANDS   16       /* a package lists at most this many candidates ... */
 #define SLIP_PKG_NROWMAX 256      /* ... of a pattern of at most this many rows */
-#define SLIP_PKG_HDR     0        /* 64-bit {k+1, version}: 1 being written, 2 valid, 3 retracted */
+#define SLIP_PKG_HDR     0        /* 64-bit {k+1, version}: even = valid, odd = being written or retracted; a column may export again */
 #define SLIP_PKG_STAMP   2
 #define SLIP_PKG_NROWS   3
 #define SLIP_PKG_SUMS    4        /* SLIP_PP_WORDS words */
 #define SLIP_PKG_STAMP0  18
+#define SLIP_PKG_VER     19       /* the version the sums belong to (every candidate record carries it too) */
 #define SLIP_PKG_OUT     32       /* the outcome: a 128-byte line of its own */
-#define SLIP_PKG_CAND    64       /* 5 words per candidate */
+#define SLIP_PKG_CAND    64       /* 6 words per candidate: table index, value (2), aux, position, version */
 #define SLIP_PKG_ROWS    160
 #define SLIP_PKG_WORDS   448
 
@@ -1033,6 +1036,101 @@ SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int
     return err_ ? -1 : ge;
 }
 
+/* ------------------------------------------------------------------ */
+/* Helping with a long update queue.  The updates of one source on the rows of a column are independent wave items; when
+ * the source arrives late (the row became pivotal a few columns before k) they are the critical path of the whole
+ * factorisation while most workers wait for their turn.  The owner publishes such a queue as a JOB in its slot of P.jobs;
+ * workers that are waiting take items from it with an atomic counter and run them on the OWNER's private x rows.
+ * Slot (words): 0 gate = open bit + 256 * helpers inside (atomics only); 2 kind, 3 j, 4 jn, 5 k, 6-7 m0, 8 items, 11 error;
+ * 16 next item; 32.. the items.  Visibility: the owner writes its dirty lines back (agent release) before it opens the
+ * gate; a helper invalidates (agent acquire) when it enters and writes back before it leaves; the owner closes the gate,
+ * waits for the helpers to leave, writes back and invalidates.  Rows share cache lines: the L2s write back the bytes
+ * they own. */
+/* Spins are bounded by ITERATION counts (each iteration sleeps): a wait that is never answered ends the launch
+ * with SLIPDEV_INTERNAL instead of hanging the device. */
+#define SLIP_SPIN_LIMIT 40000000ull
+#define SLIP_JOB_WORDS      (32 + 2 * SLIP_WORK_CAP)
+#ifndef SLIP_FARM_MIN_ITEMS
+#define SLIP_FARM_MIN_ITEMS 16          /* ... and shorter queues neither */
+#endif
+#ifndef SLIP_FARM_NEAR_DIV
+#define SLIP_FARM_NEAR_DIV  1125        /* ... and only when the column's turn comes before the worker alone would be done */
+#endif
+#ifndef SLIP_FARM_MAX_HELPERS
+#define SLIP_FARM_MAX_HELPERS 12         /* every helper costs its XCD an L2 invalidate and a write-back */
+#endif
+#ifndef SLIP_FARM_MIN_COST
+#define SLIP_FARM_MIN_COST  8192        /* items * limbs(rho)^2 below which a queue is not worth publishing */
+#endif
+
+/* take items until none is left (all waves of the calling workgroup); items: the owner's list in LDS, or null = the job's copy */
+SLIP_DEV int slip_farm_items(const SlipParams &P, uint32_t *jb, int kind, int j, int jn, int k, int64_t m0, int nq, const uint32_t *wl,
+                             dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    int err = 0, cnt = 0;
+    for (;;) {
+        int t = 0;
+        if (slip_lane() == 0) t = slip_agent_add_i32((int32_t *)(jb + 16), 1);
+        t = (int) slip_bcast0_u32((uint32_t) t);
+        if (t >= nq) break;
+        uint32_t it[2];
+        if (wl) { it[0] = wl[2 * t]; it[1] = wl[2 * t + 1]; }
+        else { it[0] = slip_ld_u32(jb + 32 + 2 * t); it[1] = slip_ld_u32(jb + 32 + 2 * t + 1); }
+        const int e = slip_run_item_out(&P, kind, j, jn, k, m0, it, 0, b0, b1, b2);
+        if (e) err = e;
+        cnt++;
+    }
+    if (!wl && cnt && slip_lane() == 0) slip_agent_add_u64(&P.st->c_farm, (unsigned long long) cnt << 32);
+    return err;
+}
+
+/* thread 0 of a waiting worker: is there a job to help with?  returns slot + 1, or 0 */
+SLIP_DEV int slip_farm_peek(const SlipParams &P, SlipState *st)
+{
+    if (!P.farm) return 0;
+    const int h = slip_ld_i32(&st->farm_hint);
+    if (h <= 0 || h - 1 == P.worker || h > P.nworkers) return 0;
+    return (slip_ld_u32(P.jobs + (int64_t)(h - 1) * SLIP_JOB_WORDS) & 1u) ? h : 0;
+}
+
+/* all threads of a waiting worker: help with the job in `slot` */
+SLIP_DEV void slip_farm_help(const SlipParams &P, SlipState *st, uint32_t *lds, int slot, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    uint32_t *jb = P.jobs + (int64_t) slot * SLIP_JOB_WORDS;
+    (void) st;
+    slip_block_sync();
+    if (slip_tid() == 0) {
+        const int old = slip_agent_add_i32((int32_t *) jb, 256);
+        const int in = (old & 1) && (old >> 8) < SLIP_FARM_MAX_HELPERS;
+        sv[SV_TMP2] = in;
+        if (!in) slip_agent_add_i32((int32_t *) jb, -256);
+    }
+    slip_block_sync();
+    if (!sv[SV_TMP2]) return;
+    if (slip_wave() == 0) slip_agent_acquire();
+    slip_block_sync();
+    const int kind = (int) slip_ld_u32(jb + 2), j = (int) slip_ld_u32(jb + 3), jn = (int) slip_ld_u32(jb + 4), k = (int) slip_ld_u32(jb + 5);
+    const int64_t m0 = (int64_t) slip_ld_u64((const uint64_t *)(jb + 6));
+    const int nq = (int) slip_ld_u32(jb + 8);
+    /* the items work on the owner's private rows: this worker's parameter block points there for the duration */
+    SlipParams &Pm = const_cast<SlipParams &>(P);
+    SlipRow *my_xrow = P.xrow; uint32_t *my_xd = P.xd;
+    slip_block_sync();
+    Pm.xrow = my_xrow + (int64_t)(slot - P.worker) * P.priv_rows;
+    Pm.xd = my_xd + (int64_t)(slot - P.worker) * P.priv_rows * P.xcap;
+    slip_block_sync();
+    const int e = slip_farm_items(P, jb, kind, j, jn, k, m0, nq, (const uint32_t *) 0, b0, b1, b2);
+    if (e && slip_lane() == 0) slip_st_u32(jb + 11, (uint32_t) e);
+    slip_vm_drain();
+    slip_block_sync();
+    Pm.xrow = my_xrow; Pm.xd = my_xd;
+    if (slip_wave() == 0) slip_agent_release();
+    slip_block_sync();
+    if (slip_tid() == 0) slip_agent_add_i32((int32_t *) jb, -256);
+    slip_block_sync();
+}
+
 /* drain a queue of wave-level items with this workgroup's waves; errors land in sv[SV_ERR].
  * Called by all threads after a workgroup barrier; returns after a workgroup barrier with every item done. */
 SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, int jn, int k, int64_t m0, int nq,
@@ -1040,6 +1138,41 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
 {
     const int lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    /* (only a column whose turn is near: further away the worker has the time, and every helper costs its XCD an L2 write-back
+     * and invalidate) */
+    if (P.farm && kind == 1 && nq >= SLIP_FARM_MIN_ITEMS && !sv[SV_ERR]) {
+        const int lr = slip_limbs(slip_ld_piv(&P.piv[jn]).len);
+        /* the queue alone takes about nq * 8 lr^2 / waves cycles; the frontier moves a column every few microseconds */
+        const int64_t cost = (int64_t) nq * lr * lr;
+        if (cost >= SLIP_FARM_MIN_COST && (SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
+            /* a long queue of long updates: open it to the workers that are waiting */
+            const int tid = slip_tid(), T = slip_nthreads();
+            uint32_t *jb = P.jobs + (int64_t) P.worker * SLIP_JOB_WORDS;
+            for (int c = tid; c < 2 * nq; c += T) slip_st_u32(jb + 32 + c, wl[c]);
+            if (tid == 0) {
+                slip_st_u32(jb + 2, (uint32_t) kind); slip_st_u32(jb + 3, (uint32_t) j); slip_st_u32(jb + 4, (uint32_t) jn); slip_st_u32(jb + 5, (uint32_t) k);
+                slip_st_u64((uint64_t *)(jb + 6), (uint64_t) m0); slip_st_u32(jb + 8, (uint32_t) nq); slip_st_u32(jb + 11, 0u); slip_st_u32(jb + 16, 0u);
+            }
+            slip_vm_drain();
+            slip_block_sync();
+            if (tid == 0) { slip_agent_release(); slip_agent_add_i32((int32_t *) jb, 1); slip_st_i32(&P.st->farm_hint, P.worker + 1); slip_agent_add_u64(&P.st->c_farm, 1ull); }
+            const int e = slip_farm_items(P, jb, kind, j, jn, k, m0, nq, wl, b0, b1, b2);
+            if (e && lane == 0) sv[SV_ERR] = e;
+            slip_vm_drain();
+            slip_block_sync();
+            if (tid == 0) {
+                slip_agent_add_i32((int32_t *) jb, -1);                          /* closed: nobody new gets in */
+                if (slip_ld_i32(&P.st->farm_hint) == P.worker + 1) slip_st_i32(&P.st->farm_hint, 0);
+                unsigned long long spins = 0;
+                while ((slip_agent_add_i32((int32_t *) jb, 0) >> 8) != 0) { slip_sleep_short(); if (++spins > SLIP_SPIN_LIMIT) { sv[SV_ERR] = SLIPDEV_INTERNAL; break; } }
+                const int he = (int) slip_ld_u32(jb + 11);
+                if (he) sv[SV_ERR] = he;
+                slip_agent_release(); slip_agent_acquire();                      /* the helpers' results, next to what this CU wrote */
+            }
+            slip_block_sync();
+            return;
+        }
+    }
     if (!sv[SV_ERR])
         for (int t = wave; t < nq; t += nw) {
             const int e = slip_run_item_out(&P, kind, j, jn, k, m0, wl, t, b0, b1, b2);

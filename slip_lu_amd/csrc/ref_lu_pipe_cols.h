@@ -3,9 +3,6 @@
 #ifndef SLIP_REF_LU_PIPE_COLS_H
 #define SLIP_REF_LU_PIPE_COLS_H
 
-/* Spins are bounded by ITERATION counts (each iteration sleeps): a wait that is never answered ends the launch
- * with SLIPDEV_INTERNAL instead of hanging the device. */
-#define SLIP_SPIN_LIMIT 40000000ull
 #ifdef SLIP_PROFILING
 #define SLIP_TR(i) do { if (tid == 0) { const unsigned long long n_ = slip_clock(); trs_[i] = (int32_t)(n_ - trp_); trp_ = n_; } } while (0)
 #else
@@ -22,7 +19,7 @@ SLIP_DEV void slip_raise_stop(SlipState *st, int k, int status) { slip_agent_min
 /* Wait until the commit frontier reaches `need` (need <= k).  Called by all threads; returns the frontier, or -1 when
  * column k can never commit (an earlier column stopped the factorisation, or a wait timed out).  once: one look only
  * (the frontier as it is, possibly below `need`). */
-SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, int once = 0)
+SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, int once = 0, const SlipParams *Pf = (const SlipParams *) 0)
 {
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     slip_block_sync();
@@ -34,6 +31,8 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, i
             const int F = slip_ld_frontier(st, &pr);
             if (F >= need) { res = F; sv[SV_TMP3] = pr; break; }       /* pr = row_perm[F-1], for free */
             if (once) { res = F; break; }                               /* a look, not a wait: the caller has something to do meanwhile */
+            /* nothing to do but wait: is another worker's update queue open to helpers?  (-2 - slot: the caller helps, then waits again) */
+            if (Pf) { const int h = slip_farm_peek(*Pf, st); if (h) { res = -1 - h; break; } }
             const int64_t stop = slip_ld_i64(&st->stop);
             if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             /* the further from its turn, the longer between polls: the frontier word is one line for the whole chip */
@@ -273,16 +272,21 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
 #ifdef SLIP_EMU_TRACE
                     if (tid == 0) fprintf(stderr, "worker: col %d prepass valid %d ncand %d nonS %d nrows %d committer %d\n", k, (int) sv[SV_PP], (int) sv[SV_PP + 1], (int) sv[SV_PP + 12], (int) sv[SV_NROWS], P.committer);
 #endif
-                    if (P.committer && sv[SV_PP] && !sv[SV_PP + 12] && !sv[SV_PKGVER] && sv[SV_NROWS] <= SLIP_PKG_NROWMAX && sv[SV_PP + 1] <= SLIP_PKG_CANDS) {
+                    if (P.committer && sv[SV_PP] && !sv[SV_PP + 12] && sv[SV_PKGVER] < 120 && k < (1 << 24) - 1 && sv[SV_NROWS] <= SLIP_PKG_NROWMAX && sv[SV_PP + 1] <= SLIP_PKG_CANDS) {
                         if (tid == 0) sv[SV_PKGF] = Fl;
                         slip_export_package(P, k, lds, Fl);
 #ifdef SLIP_PROFILING
                         if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 1] = (int32_t) slip_realtime();  /* time line 1: package exported */
 #endif
                     }
-                    Fn = slip_wait_frontier(st, lds, Fl + 1, k);
+                    Fn = -2;
                 }
-            } else Fn = slip_wait_frontier(st, lds, Fl + 1, k);
+            } else Fn = -2;
+            /* the wait proper; a worker that waits helps with the long update queues of others (slip_farm_help) */
+            while (Fn <= -2) {
+                Fn = slip_wait_frontier(st, lds, Fl + 1, k, 0, &P);
+                if (Fn <= -2) slip_farm_help(P, st, lds, -Fn - 2, b0, b1, b2);
+            }
 #ifdef SLIP_PROFILING
             *t_last = slip_clock(); t_wait[0] += *t_last - tw0_; t_wait[2] = slip_realtime();
 #endif
@@ -623,16 +627,17 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
 #endif
     const int packaged = P.committer && try_early && sv[SV_PKGX];
     slip_block_sync();                                   /* (thread 0 clears the flag below) */
-    if (packaged) {
+    if (packaged) for (;;) {
         const uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
         if (tid == 0) {
             int res; unsigned long long spins = 0;
             for (;;) {
-                const int v = (int) slip_ld_u32(pk + SLIP_PKG_OUT);
-                if (v == k + 1) { res = 1; break; }
-                if (v == -(k + 1)) { res = 0; break; }
+                const int v = (int) slip_ld_u32(pk + SLIP_PKG_OUT), mine_ = (sv[SV_PKGVER] << 24) | (k + 1);      /* a verdict names the version it is about */
+                if (v == mine_) { res = 1; break; }
+                if (v == -mine_) { res = 0; break; }
                 const int64_t stop = slip_ld_i64(&st->stop);
                 if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
+                { const int h = slip_farm_peek(P, st); if (h) { res = -1 - h; break; } }
                 slip_sleep_short();
                 if (++spins > SLIP_SPIN_LIMIT) { slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
             }
@@ -640,11 +645,13 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             if (res == 0) sv[SV_PKGX] = 0;               /* rejected: this worker commits the column itself */
         }
         slip_block_sync();
+        if (sv[SV_TMP2] <= -2) { const int slot_ = -sv[SV_TMP2] - 2; slip_farm_help(P, st, lds, slot_, b0, b1, b2); continue; }
 #ifdef SLIP_PROFILING
         if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 3] = (int32_t) slip_realtime();      /* time line 3: verdict seen */
 #endif
         if (sv[SV_TMP2] < 0) return SLIPDEV_ABORTED;
         adopted = sv[SV_TMP2];
+        break;
     }
     const bool fastc = !adopted && try_early && nw >= 2 && sv[SV_PP] != 0;
     uint32_t *ppcl = work + SLIP_CAND_CAP;                 /* the pre-pass's candidate list (table indices) */

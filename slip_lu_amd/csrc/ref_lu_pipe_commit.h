@@ -29,8 +29,9 @@
 #ifndef SLIP_REF_LU_PIPE_COMMIT_H
 #define SLIP_REF_LU_PIPE_COMMIT_H
 
-/* the worker's side: export the package the pre-pass has just prepared (all threads; barriers inside).  A column exports
- * at most once: the package of {k+1, version 2} never changes, so the committer may read it in one round of loads. */
+/* the worker's side: export the package the pre-pass has just prepared (all threads; barriers inside).  A column may
+ * export again after a retraction: the version in the header, in the sums and in every candidate record tells the
+ * committer which package it is looking at (it reads header and contents in separate rounds of loads). */
 SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *lds, const int Fl)
 {
     const int tid = slip_tid(), T = slip_nthreads();
@@ -40,24 +41,26 @@ SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *ld
     const uint32_t *cl = lds + SLIP_LDS_WORK + SLIP_CAND_CAP;
     uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
     const int nrows = sv[SV_NROWS], ncand = sv[SV_PP + 1];
-    if (tid == 0) { slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), (1ull << 32) | (uint32_t)(k + 1)); slip_vm_drain(); }
+    const uint32_t ver = ((uint32_t) sv[SV_PKGVER] | 1u) + 1u;          /* 2, 4, 6, ... */
+    if (tid == 0) { slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t)(ver - 1u) << 32) | (uint32_t)(k + 1)); slip_vm_drain(); }
     slip_block_sync();
     for (int t = tid; t < nrows; t += T) slip_st_u32(pk + SLIP_PKG_ROWS + t, f_row[t]);
     for (int c = tid; c < ncand; c += T) {
         const int t = (int) cl[c];
-        uint32_t *cr = pk + SLIP_PKG_CAND + 5 * c;
+        uint32_t *cr = pk + SLIP_PKG_CAND + 6 * c;
         slip_st_u32(cr, (uint32_t) t); slip_st_u32(cr + 1, f_k0[t]); slip_st_u32(cr + 2, f_k1[t]); slip_st_u32(cr + 3, f_aux[t]); slip_st_u32(cr + 4, f_pos[t]);
+        slip_st_u32(cr + 5, ver);
     }
     if (tid < SLIP_PP_WORDS) slip_st_u32(pk + SLIP_PKG_SUMS + tid, (uint32_t) sv[SV_PP + tid]);
     if (tid == SLIP_PP_WORDS) {
         slip_st_u32(pk + SLIP_PKG_STAMP, (uint32_t) Fl); slip_st_u32(pk + SLIP_PKG_STAMP0, (uint32_t) Fl);
-        slip_st_u32(pk + SLIP_PKG_NROWS, (uint32_t) nrows); slip_st_u32(pk + SLIP_PKG_OUT, 0u);
+        slip_st_u32(pk + SLIP_PKG_NROWS, (uint32_t) nrows); slip_st_u32(pk + SLIP_PKG_VER, ver); slip_st_u32(pk + SLIP_PKG_OUT, 0u);
     }
     slip_vm_drain();
     slip_block_sync();
     if (tid == 0) {
-        slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), (2ull << 32) | (uint32_t)(k + 1));
-        sv[SV_PKGVER] = 2; sv[SV_PKGX] = 1;
+        slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t) ver << 32) | (uint32_t)(k + 1));
+        sv[SV_PKGVER] = (int32_t) ver; sv[SV_PKGX] = 1;
     }
     slip_block_sync();
 }
@@ -66,8 +69,9 @@ SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *ld
 SLIP_DEV void slip_retract_package(const SlipParams &P, const int k, volatile int32_t *sv)
 {
     uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
-    slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), (3ull << 32) | (uint32_t)(k + 1));
-    sv[SV_PKGVER] = 3; sv[SV_PKGX] = 0;
+    const uint32_t ver = (uint32_t) sv[SV_PKGVER] | 1u;
+    slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t) ver << 32) | (uint32_t)(k + 1));
+    sv[SV_PKGVER] = (int32_t) ver; sv[SV_PKGX] = 0;
 }
 
 /* one candidate: the one-limb value a (nd digits) times rho[k-1] (in registers) -> LDS slot, search key, length */
@@ -98,7 +102,7 @@ template <int D> SLIP_DEV void slip_commit_mul(const WR<D> &Mr, uint32_t a0, uin
 /* LDS of the committer, words from lds + SLIP_LDS_WORK (the lists, tables and keys of a column worker: 12288 words) */
 #define SLIP_CB          8                  /* columns per batch */
 #define SLIP_CB_RING     1024               /* swaps the committer remembers */
-#define SLIP_CBW         (32 + 5 * SLIP_PKG_CANDS + SLIP_PKG_NROWMAX)      /* one batch column: sums, candidates, rows */
+#define SLIP_CBW         (32 + 6 * SLIP_PKG_CANDS + SLIP_PKG_NROWMAX)      /* one batch column: sums, candidates, rows */
 #define SLIP_CB_SLOTW    262                /* a product of a one-limb value and a pivot of at most 256 digits, whole limbs */
 
 /* the kernel body of the committer (block 0 of a launch with P.committer set).
@@ -125,10 +129,11 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
     SlipPiv *Mrec = (SlipPiv *)(lds + SLIP_LDS_SCAN);            /* rho[j-1]'s record */
     const int scheme = P.pivot_scheme;
     const int kind = (scheme == 4 || scheme == 5) ? 1 : 0;
-    enum { C_K = SV_PP + SLIP_PP_WORDS, C_HAVE, C_GO, C_RING0, C_REJ, C_ST, C_LASTPR };
+    enum { C_K = SV_PP + SLIP_PP_WORDS, C_HAVE, C_GO, C_RING0, C_REJ, C_REJV, C_ST, C_LASTPR };
+    uint32_t *hver = cpos + SLIP_PKG_CANDS;                      /* the versions of the batch's packages as the poll saw them */
     if (tid == 0) {
         int pr_; sv[C_K] = slip_ld_frontier(st, &pr_);
-        sv[C_HAVE] = 0; sv[C_RING0] = sv[C_K]; sv[C_REJ] = -1;
+        sv[C_HAVE] = 0; sv[C_RING0] = sv[C_K]; sv[C_REJ] = -1; sv[C_REJV] = 0;
     }
     slip_block_sync();
 #ifdef SLIP_PROFILE_COMMIT
@@ -167,7 +172,9 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 const int j = kc + lane;
                 uint64_t h = 0;
                 if (lane < SLIP_CB && j < P.k_stop && (stop >> 8) > (int64_t) j) h = slip_ld_u64((const uint64_t *)(P.pkg + (int64_t)(j % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_HDR));
-                const int rdy = (uint32_t) h == (uint32_t)(j + 1) && (uint32_t)(h >> 32) == 2u && j != sv[C_REJ];
+                const uint32_t hv = (uint32_t)(h >> 32);
+                const int rdy = (uint32_t) h == (uint32_t)(j + 1) && hv >= 2u && !(hv & 1u) && !(j == sv[C_REJ] && hv == (uint32_t) sv[C_REJV]);
+                if (lane < SLIP_CB) hver[lane] = hv;
                 const int nb = slip_ctz64(~slip_ballot(rdy));
                 if (nb >= 1) { go = nb < SLIP_CB ? nb : SLIP_CB; break; }
                 slip_sleep_short();
@@ -192,8 +199,9 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             else if (lane == 16) cb[16] = slip_ld_u32(pk + SLIP_PKG_NROWS);
             else if (lane == 17) cb[17] = (uint32_t) slip_ld_i32(&P.row_perm[j]);
             else if (lane == 18) cb[18] = 0u;
-            for (int c = lane; c < 5 * SLIP_PKG_CANDS; c += SLIP_WAVE) cb[32 + c] = slip_ld_u32(pk + SLIP_PKG_CAND + c);
-            for (int c = lane; c < SLIP_PKG_NROWMAX; c += SLIP_WAVE) cb[32 + 5 * SLIP_PKG_CANDS + c] = slip_ld_u32(pk + SLIP_PKG_ROWS + c);
+            else if (lane == 19) cb[19] = slip_ld_u32(pk + SLIP_PKG_VER);
+            for (int c = lane; c < 6 * SLIP_PKG_CANDS; c += SLIP_WAVE) cb[32 + c] = slip_ld_u32(pk + SLIP_PKG_CAND + c);
+            for (int c = lane; c < SLIP_PKG_NROWMAX; c += SLIP_WAVE) cb[32 + 6 * SLIP_PKG_CANDS + c] = slip_ld_u32(pk + SLIP_PKG_ROWS + c);
         }
         if (!have) {
             if (tid == T - 1) sv64[SV_LNZ / 2] = slip_ld_i64(&P.Lp[kc]);
@@ -215,9 +223,11 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             uint32_t *cb = base + i * SLIP_CBW;
             const int nrows = (int) cb[16], ncand = (int) cb[1], stamp = (int) cb[14], stamp0 = (int) cb[15];
             int hit = nrows < 1 || nrows > SLIP_PKG_NROWMAX || ncand < 1 || ncand > SLIP_PKG_CANDS || stamp < stamp0 || stamp > j
-                      || stamp0 < sv[C_RING0] || j - stamp0 > SLIP_CB_RING - SLIP_CB || cb[12] != 0;
+                      || stamp0 < sv[C_RING0] || j - stamp0 > SLIP_CB_RING - SLIP_CB || cb[12] != 0 || cb[19] != hver[i];
+            /* (a package being rewritten: its parts carry different versions -- it will be offered again) */
+            if (!hit && lane < ncand && cb[32 + 6 * lane + 5] != hver[i]) hit = 1;
             if (!hit) {
-                const uint32_t *rows = cb + 32 + 5 * SLIP_PKG_CANDS;
+                const uint32_t *rows = cb + 32 + 6 * SLIP_PKG_CANDS;
                 uint32_t r0 = lane < nrows ? rows[lane] : 0xFFFFFFFFu, r1 = lane + 64 < nrows ? rows[lane + 64] : 0xFFFFFFFFu;
                 uint32_t r2 = lane + 128 < nrows ? rows[lane + 128] : 0xFFFFFFFFu, r3 = lane + 192 < nrows ? rows[lane + 192] : 0xFFFFFFFFu;
                 for (int c = stamp; c < kc; c++) {
@@ -236,7 +246,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         for (int i = 0; i < nb; i++) {
             const int j = kc + i, col = P.q[j];
             uint32_t *cb = base + i * SLIP_CBW;
-            const uint32_t *cands = cb + 32, *rows = cb + 32 + 5 * SLIP_PKG_CANDS;
+            const uint32_t *cands = cb + 32, *rows = cb + 32 + 6 * SLIP_PKG_CANDS;
             uint32_t *pk = P.pkg + (int64_t)(j % P.nworkers) * SLIP_PKG_WORDS;
             const int nrows = (int) cb[16], ncand = (int) cb[1], stamp0 = (int) cb[15];
             const SlipPiv M = *Mrec;
@@ -280,18 +290,18 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                      * stamp0, or where the LAST swap since then that displaced the row put it */
                     const int nev = j - stamp0;
                     for (int c = 0; c < ncand; c++) {
-                        const uint32_t r = rows[cands[5 * c]];
+                        const uint32_t r = rows[cands[6 * c]];
                         int last = -1;
                         for (int e0 = 0; e0 < nev; e0 += SLIP_WAVE) {
                             const int e = stamp0 + e0 + lane;
                             const uint64_t m = slip_ballot(e < j && ring_disp[e & (SLIP_CB_RING - 1)] == r);
                             if (m) last = stamp0 + e0 + 63 - slip_clz64(m);
                         }
-                        if (lane == 0) cpos[c] = last >= 0 ? ring_opos[last & (SLIP_CB_RING - 1)] : cands[5 * c + 4];
+                        if (lane == 0) cpos[c] = last >= 0 ? ring_opos[last & (SLIP_CB_RING - 1)] : cands[6 * c + 4];
                     }
                     /* products of a one-limb pivot: in the lane */
                     if (lm <= 2 && lane < ncand) {
-                        const uint64_t xv = (uint64_t) cands[5 * lane + 1] | ((uint64_t) cands[5 * lane + 2] << 32);
+                        const uint64_t xv = (uint64_t) cands[6 * lane + 1] | ((uint64_t) cands[6 * lane + 2] << 32);
                         const slip_u128 y = (slip_u128) xv * M.lo;
                         const int yb = slip_bits128(y), yl = (yb + 31) >> 5;
                         dig_t *sl = stage + lane * slotw;
@@ -312,7 +322,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             if (lm > 2) {
                 const int Dm = (lm + 2 + 63) >> 6;
                 for (int c = wave; c < ncand; c += nw) {
-                    const uint32_t a0 = cands[5 * c + 1], a1 = cands[5 * c + 2]; const int nd = (int)((cands[5 * c + 3] >> 12) & 3u);
+                    const uint32_t a0 = cands[6 * c + 1], a1 = cands[6 * c + 2]; const int nd = (int)((cands[6 * c + 3] >> 12) & 3u);
                     uint64_t key; int len;
                     if (Dm <= 1) slip_commit_mul<1>(wr_load<1>(Ms, lm), a0, a1, nd, stage + c * slotw, kind, &key, &len);
                     else if (Dm == 2) slip_commit_mul<2>(wr_load<2>(Ms, lm), a0, a1, nd, stage + c * slotw, kind, &key, &len);
@@ -353,8 +363,8 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); the worker listed the diagonal row when it is
                  * a nonzero non-pivotal row of the pattern */
                 const int diag_t = (int) cb[13] - 1;
-                if (!est && (scheme == 1 || scheme == 3 || scheme == 4) && diag_t >= 0 && (int) cands[5 * bc] != diag_t) {
-                    const uint64_t dm = slip_ballot(lane < ncand && (int) cands[5 * lane] == diag_t);
+                if (!est && (scheme == 1 || scheme == 3 || scheme == 4) && diag_t >= 0 && (int) cands[6 * bc] != diag_t) {
+                    const uint64_t dm = slip_ballot(lane < ncand && (int) cands[6 * lane] == diag_t);
                     const int dc = dm ? slip_ctz64(dm) : -1;
                     if (dc < 0) est = -1;                       /* not among the candidates it sent: the worker decides */
                     else if (scheme == 1 || P.tol_mode == 0) bc = dc;
@@ -382,8 +392,8 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 else {
                     /* stage 1, issued and not waited for: the pivot's digits written through, its record, the swap and its log,
                      * the column pointers, the outcome for the worker */
-                    const int e_pivrow = (int) rows[cands[5 * bc]], e_pivpos = (int) cpos[bc];
-                    const uint32_t ax = cands[5 * bc + 3];
+                    const int e_pivrow = (int) rows[cands[6 * bc]], e_pivpos = (int) cpos[bc];
+                    const uint32_t ax = cands[6 * bc + 3];
                     const int lp_ = (int) clen[bc];
                     const int neg = (int)((ax >> 14) & 1u) ^ (M.len < 0);
                     uint64_t key = (uint64_t) ck0[bc] | ((uint64_t) ck1[bc] << 32);
@@ -431,12 +441,16 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         /* (d) everything issued above has left; then the verdicts and the frontier */
         if (wave == 0) {
             slip_vm_drain();
-            if (lane < nbc) slip_st_u32(P.pkg + (int64_t)((kc + lane) % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_OUT, (uint32_t)(kc + lane + 1));
+            if (lane < nbc) slip_st_u32(P.pkg + (int64_t)((kc + lane) % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_OUT, (hver[lane] << 24) | (uint32_t)(kc + lane + 1));
 #ifdef SLIP_PROFILE_PHASES
             if (lane < nbc) P.dbg[18 * (int64_t) P.n + 6 * (int64_t)(kc + lane) + 2] = (int32_t) slip_realtime();  /* time line 2: committed by the committer */
 #endif
             if (lane == 0) {
-                if (rej >= 0) { slip_st_u32(P.pkg + (int64_t)(rej % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_OUT, (uint32_t)(-(rej + 1))); sv[C_REJ] = rej; }
+                if (rej >= 0) {
+                    const uint32_t rv = hver[rej - kc];
+                    slip_st_u32(P.pkg + (int64_t)(rej % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_OUT, (uint32_t)(-(int32_t)((rv << 24) | (uint32_t)(rej + 1))));
+                    sv[C_REJ] = rej; sv[C_REJV] = (int32_t) rv;
+                }
                 if (nbc > 0) {
                     slip_st_frontier(st, kc + nbc, sv[C_LASTPR]);
                     slip_agent_add_u64(&st->c_short, (unsigned long long) nbc | ((unsigned long long) nbc << 32));      /* high word: by the committer */

@@ -257,6 +257,7 @@ struct slip_hip_factor {
     int32_t waves, lds_words, bitmap_in_lds, scratch_in_lds;
     int32_t nworkers;      /* column workers = workgroups of a launch; private arrays are sized for this many */
     int32_t no_committer;  /* diagnostics: every column is committed by its own worker */
+    int32_t no_farm;       /* diagnostics: long update queues are not opened to other workers */
     int32_t last_status, window_end, launches;
     int32_t factors_only;  /* built from given factors (slip_hip_factor_from_factors): solve only, no A */
     double kernel_ms, solve_ms;
@@ -393,8 +394,10 @@ static int alloc_x(slip_hip_factor *f, int32_t xcap, int keep_rows)
     if (dev_alloc(&P->gbitmap, f->bitmap_in_lds ? 1 : W * ((int64_t) P->bm_words + 64))) return SLIP_HIP_OUT_OF_MEMORY;
     if (!keep_rows || !P->pkg) {
         if (P->pkg) hipFree(P->pkg);
-        P->pkg = NULL;
-        if (dev_alloc(&P->pkg, W * (int64_t) SLIP_PKG_WORDS)) return SLIP_HIP_OUT_OF_MEMORY;
+        if (P->jobs) hipFree(P->jobs);
+        P->pkg = NULL; P->jobs = NULL;
+        if (dev_alloc(&P->pkg, W * (int64_t) SLIP_PKG_WORDS) || dev_alloc(&P->jobs, W * (int64_t) SLIP_JOB_WORDS)) return SLIP_HIP_OUT_OF_MEMORY;
+        if (hipMemset(P->jobs, 0, (size_t) W * SLIP_JOB_WORDS * 4) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
     }
     return 0;
 }
@@ -437,7 +440,7 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
     hipFree(P->piv); hipFree(P->invd);
     hipFree(P->Lp); hipFree(P->Lo); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
     hipFree(P->Up); hipFree(P->Uo); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
-    hipFree(P->Lready); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg); hipFree(P->pkg); hipFree(P->sw_row); hipFree(P->sw_pos);
+    hipFree(P->Lready); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg); hipFree(P->pkg); hipFree(P->jobs); hipFree(P->sw_row); hipFree(P->sw_pos);
     hipFree(f->ds); hipFree(f->ident);
     rescale_drop(f);
     if (f->ev0) hipEventDestroy(f->ev0);
@@ -453,6 +456,7 @@ static void apply_options(slip_hip_factor *f, const slip_hip_options &opt)
     f->nworkers = opt.workers > 0 ? opt.workers : 0;      /* 0: chosen in alloc_x once the LDS need is known */
     f->P.no_early = opt.reserved & 1;
     f->no_committer = (opt.reserved >> 1) & 1;
+    f->no_farm = (opt.reserved >> 2) & 1;
     if (f->nworkers > 4096) f->nworkers = 4096;
 }
 
@@ -621,7 +625,8 @@ extern "C" void slip_emu_set_seed(unsigned long long s) { slip_emu_seed = s; }
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
     f->P.k0 = f->hs.F; f->P.t0 = f->hs.ticket;
-    f->hs.stop = INT64_MAX; f->hs.exited = 0;
+    f->hs.stop = INT64_MAX; f->hs.exited = 0; f->hs.farm_hint = 0;
+    f->P.st = f->ds;
     { const int e = upload_state(f, stream); if (e) return e; }
     /* no more workers than columns left */
     int32_t W = f->nworkers;
@@ -632,6 +637,8 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
     if (W < 2) f->P.committer = 0;
     f->P.nworkers = W;
     if (f->P.committer) CK(hipMemsetAsync(f->P.pkg, 0, (size_t) W * SLIP_PKG_WORDS * 4, stream));
+    f->P.farm = W >= 2 && !f->no_farm && f->P.jobs != NULL;
+    if (f->P.farm) CK(hipMemsetAsync(f->P.jobs, 0, (size_t) W * SLIP_JOB_WORDS * 4, stream));
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;
@@ -826,6 +833,7 @@ static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, int32_t *rhs
 {
     f->P.t0 = f->hs.ticket;
     f->hs.stop = INT64_MAX; f->hs.exited = 0;
+    f->P.farm = 0; f->P.committer = 0; f->P.st = f->ds;
     { const int e = upload_state(f, stream); if (e) return e; }
     int32_t W = f->nworkers;
     if (W > A.nrhs) W = A.nrhs;
@@ -1131,6 +1139,7 @@ extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)
     o->kernel_ms = f->kernel_ms; o->launches = f->launches; o->xcap_digits = f->P.xcap;
     o->limb_macs = (int64_t) h->c_macs; o->workers = f->nworkers; o->waves = f->waves; o->lds_bytes = f->lds_words * 4;
     o->short_commits = (int32_t)(uint32_t) h->c_short; o->committer_commits = (int32_t)(h->c_short >> 32);
+    o->farm_jobs = (int32_t)(uint32_t) h->c_farm; o->farm_items = (int32_t)(h->c_farm >> 32);
     return SLIP_HIP_OK;
 }
 

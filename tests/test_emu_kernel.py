@@ -19,6 +19,12 @@ def emu_lib():
     return EMU
 
 
+@pytest.fixture(scope="module")
+def emu_farm_lib():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libslip_emu_farm.so"])
+    return os.path.join(ROOT, "tests", "emu", "libslip_emu_farm.so")
+
+
 def set_seed(emu_lib, seed):
     """the interleaving of the emulated workgroups is a seeded pseudo-random schedule (tests/emu/fiber_emu.h)"""
     import ctypes
@@ -39,6 +45,20 @@ def test_emulated_kernel_matches_reference(emu_lib, name, waves, workers):
         res = sl.factorize(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"],
                            pivot=entry["pivot"], tol=entry["tol"], kmax=entry["kmax"], limb_cap=entry["cap"],
                            waves=waves, workers=workers, lib_path=emu_lib)
+        check_against_golden(entry, fix, res)
+
+
+@pytest.mark.parametrize("name,waves,workers", [("test_mat", 2, 3), ("gen_n40", 1, 4), ("gen_n40", 2, 6), ("test_mat_p4tol", 1, 5)])
+def test_emulated_workers_help_with_update_queues(emu_farm_lib, name, waves, workers):
+    """a build in which every update queue of two or more items is opened to the waiting workers: items of one worker's
+    column run on other workgroups, on the owner's private rows (the farm protocol of ref_lu_pipe.h)"""
+    import slip_lu_amd as sl
+    entry, fix = load_case(name)
+    for seed in (1, 2, 3):
+        set_seed(emu_farm_lib, seed)
+        res = sl.factorize(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"],
+                           pivot=entry["pivot"], tol=entry["tol"], kmax=entry["kmax"], limb_cap=entry["cap"],
+                           waves=waves, workers=workers, lib_path=emu_farm_lib)
         check_against_golden(entry, fix, res)
 
 
