@@ -62,8 +62,10 @@ SLIP_DEV int slip_advance_ready(const SlipParams &P, SlipState *st)
     return f2;
 }
 
-/* Wait until the ready frontier reaches `need` (need <= the commit frontier this worker knows).  Called by all threads;
- * returns the ready frontier, or -1 when the launch is being given up. */
+/* Wait until column need-1 has published its L entries and limbs (need <= the commit frontier this worker knows): its own
+ * flag, not the contiguous ready frontier -- one heavy column that is still writing must not hold up the columns that do
+ * not read it.  Called by all threads; returns the ready frontier (possibly still below `need`: a cache of "everything
+ * below is ready"), or -1 when the launch is being given up. */
 SLIP_DEV int slip_wait_ready(const SlipParams &P, SlipState *st, uint32_t *lds, int need)
 {
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
@@ -73,7 +75,7 @@ SLIP_DEV int slip_wait_ready(const SlipParams &P, SlipState *st, uint32_t *lds, 
         unsigned long long spins = 0;
         for (;;) {
             const int f2 = slip_advance_ready(P, st);
-            if (f2 >= need) { res = f2; break; }
+            if (f2 >= need || slip_agent_add_i32(&P.Lready[need - 1], 0) != 0) { res = f2; break; }
             if ((int)(slip_ld_i64(&st->stop) & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             slip_sleep_short();
             if (++spins > SLIP_SPIN_LIMIT) { slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }

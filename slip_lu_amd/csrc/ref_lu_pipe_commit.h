@@ -129,7 +129,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
     SlipPiv *Mrec = (SlipPiv *)(lds + SLIP_LDS_SCAN);            /* rho[j-1]'s record */
     const int scheme = P.pivot_scheme;
     const int kind = (scheme == 4 || scheme == 5) ? 1 : 0;
-    enum { C_K = SV_PP + SLIP_PP_WORDS, C_HAVE, C_GO, C_RING0, C_REJ, C_REJV, C_ST, C_LASTPR };
+    enum { C_K = SV_PP + SLIP_PP_WORDS, C_HAVE, C_GO, C_RING0, C_REJ, C_REJV, C_ST, C_LASTPR, C_IM2 };
     uint32_t *hver = cpos + SLIP_PKG_CANDS;                      /* the versions of the batch's packages as the poll saw them */
     if (tid == 0) {
         int pr_; sv[C_K] = slip_ld_frontier(st, &pr_);
@@ -286,19 +286,6 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     if (P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) reject = 2;
                 }
                 if (!reject) {
-                    /* the candidates' positions (pinv as the reference has it at column j): the value the worker read at frontier
-                     * stamp0, or where the LAST swap since then that displaced the row put it */
-                    const int nev = j - stamp0;
-                    for (int c = 0; c < ncand; c++) {
-                        const uint32_t r = rows[cands[6 * c]];
-                        int last = -1;
-                        for (int e0 = 0; e0 < nev; e0 += SLIP_WAVE) {
-                            const int e = stamp0 + e0 + lane;
-                            const uint64_t m = slip_ballot(e < j && ring_disp[e & (SLIP_CB_RING - 1)] == r);
-                            if (m) last = stamp0 + e0 + 63 - slip_clz64(m);
-                        }
-                        if (lane == 0) cpos[c] = last >= 0 ? ring_opos[last & (SLIP_CB_RING - 1)] : cands[6 * c + 4];
-                    }
                     /* products of a one-limb pivot: in the lane */
                     if (lm <= 2 && lane < ncand) {
                         const uint64_t xv = (uint64_t) cands[6 * lane + 1] | ((uint64_t) cands[6 * lane + 2] << 32);
@@ -313,6 +300,30 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     }
                 }
                 if (lane == 0) sv[C_ST] = reject;
+            } else if (wave == 1) {
+                /* meanwhile, the second wave: the candidates' positions (pinv as the reference has it at column j) -- the value the
+                 * worker read at frontier stamp0, or where the LAST swap since then that displaced the row put it.  Lanes look
+                 * at the swaps, the candidates' rows come from the lanes that hold them. */
+                const uint32_t myrow = lane < ncand ? rows[cands[6 * lane]] : 0xFFFFFFFFu;
+                int last = -1;
+                for (int e0 = stamp0; e0 < j; e0 += SLIP_WAVE) {
+                    const int e = e0 + lane;
+                    const uint32_t d = e < j ? ring_disp[e & (SLIP_CB_RING - 1)] : 0xFFFFFFFEu;
+                    for (int c = 0; c < ncand; c++) {
+                        const uint64_t m = slip_ballot(d == slip_readlane(myrow, c));
+                        if (m && lane == c) last = e0 + 63 - slip_clz64(m);
+                    }
+                }
+                if (lane < ncand) cpos[lane] = last >= 0 ? ring_opos[last & (SLIP_CB_RING - 1)] : cands[6 * lane + 4];
+                /* the row at position j (the one the pivot changes places with): as loaded at the start of the batch, or the row a
+                 * swap of this batch displaced to j */
+                int intermed2 = (int) cb[17];
+                {
+                    const int e = kc + lane;
+                    const uint64_t m = slip_ballot(e < j && (int) ring_opos[e & (SLIP_CB_RING - 1)] == j);
+                    if (m) intermed2 = (int) ring_disp[(kc + 63 - slip_clz64(m)) & (SLIP_CB_RING - 1)];
+                }
+                if (lane == 0) sv[C_IM2] = intermed2;
             }
             SLIP_CT(10);
             slip_block_sync();
@@ -335,14 +346,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             slip_block_sync();
             SLIP_CT(13);
             if (wave == 0) {
-                /* the row at position j (the one the pivot changes places with): as loaded at the start of the batch, or the
-                 * row a swap of this batch displaced to j */
-                int intermed2 = (int) cb[17];
-                {
-                    const int e = kc + lane;
-                    const uint64_t m = slip_ballot(e < j && (int) ring_opos[e & (SLIP_CB_RING - 1)] == j);
-                    if (m) intermed2 = (int) ring_disp[(kc + 63 - slip_clz64(m)) & (SLIP_CB_RING - 1)];
-                }
+                const int intermed2 = sv[C_IM2];
                 /* the search: (bit length, leading bits) keys; ties compared exactly, then by position (slip_get_smallest_pivot.c:79) */
                 const uint64_t mykey = lane < ncand ? ((uint64_t) ck0[lane] | ((uint64_t) ck1[lane] << 32)) : ~0ull;
                 const uint32_t mh = slip_wave_min_u32((uint32_t)(mykey >> 32));
@@ -404,27 +408,55 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     const uint64_t lalloc = (uint64_t) nA * (uint64_t) slot + (lm > 2 ? 0ull : plimbs);
                     const dig_t *src = stage + bc * slotw;
                     const int z = slip_publish_digits((dig_t *)(P.Llimbs + poff), src, 0, lp_);
-                    if (lane == 0) {
+                    {
                         SlipPiv pr; pr.off = poff; pr.len = neg ? -lp_ : lp_; pr.bits = pbits; pr.ctz = z; pr.invlen = 0;
                         pr.lo = *(const uint64_t *) src; pr.inv64 = 0; pr.pad = 0;
                         if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
-                        slip_st_piv(&P.piv[j], pr);
-                        *Mrec = pr;
-                        slip_st_i32(&P.row_perm[j], e_pivrow); slip_st_i32(&P.row_perm[e_pivpos], intermed2);
-                        slip_st_i32(&P.pinv[e_pivrow], j); slip_st_i32(&P.pinv[intermed2], e_pivpos);
-                        slip_st_i32(&P.sw_row[j], intermed2); slip_st_i32(&P.sw_pos[j], e_pivpos);
                         const int64_t nUnz = Unz_ + (int) nUc_all + 1, nLnz = Lnz_ + nLc;
                         const int64_t nUnl = Unl_ + (int64_t)(U_l + plimbs), nLnl = Lnl_ + (int64_t) Lb_total;
-                        slip_st_i64(&P.Up[j + 1], nUnz); slip_st_i64(&P.Lp[j + 1], nLnz);
-                        slip_st_i64(&P.Uo[j + 1], nUnl); slip_st_i64(&P.Lo[j + 1], nLnl);
-                        sv64[SV_LNZ / 2] = nLnz; sv64[SV_LNL / 2] = nLnl; sv64[SV_UNZ / 2] = nUnz; sv64[SV_UNL / 2] = nUnl;
-                        slip_st_u32(pk + SLIP_PKG_OUT + 1, (uint32_t) e_pivrow); slip_st_u32(pk + SLIP_PKG_OUT + 2, (uint32_t) e_pivpos);
-                        slip_st_u32(pk + SLIP_PKG_OUT + 3, (uint32_t)(neg ? -lp_ : lp_)); slip_st_u32(pk + SLIP_PKG_OUT + 4, (uint32_t) pbits);
-                        slip_st_u64((uint64_t *)(pk + SLIP_PKG_OUT + 6), (uint64_t) poff); slip_st_u64((uint64_t *)(pk + SLIP_PKG_OUT + 8), lalloc);
-                        ring_row[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivrow; ring_disp[j & (SLIP_CB_RING - 1)] = (uint32_t) intermed2;
-                        ring_opos[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivpos;
-                        if (j + 1 - sv[C_RING0] > SLIP_CB_RING) sv[C_RING0] = j + 1 - SLIP_CB_RING;
-                        sv[C_LASTPR] = e_pivrow;
+                        /* every lane computes the same values; lane q issues store q: two store instructions instead of twenty-odd */
+                        {
+                            uint64_t *a8 = (uint64_t *) 0; uint64_t v8 = 0;
+                            uint64_t *pw = (uint64_t *) &P.piv[j];
+                            switch (lane) {
+                                case 0: a8 = pw; v8 = (uint64_t) pr.off; break;
+                                case 1: a8 = pw + 1; v8 = (uint64_t)(uint32_t) pr.len | ((uint64_t)(uint32_t) pr.bits << 32); break;
+                                case 2: a8 = pw + 2; v8 = pr.lo; break;
+                                case 3: a8 = pw + 3; v8 = (uint64_t)(uint32_t) pr.ctz; break;
+                                case 4: a8 = pw + 4; v8 = pr.inv64; break;
+                                case 5: a8 = (uint64_t *) &P.Up[j + 1]; v8 = (uint64_t) nUnz; break;
+                                case 6: a8 = (uint64_t *) &P.Lp[j + 1]; v8 = (uint64_t) nLnz; break;
+                                case 7: a8 = (uint64_t *) &P.Uo[j + 1]; v8 = (uint64_t) nUnl; break;
+                                case 8: a8 = (uint64_t *) &P.Lo[j + 1]; v8 = (uint64_t) nLnl; break;
+                                case 9: a8 = (uint64_t *)(pk + SLIP_PKG_OUT + 6); v8 = (uint64_t) poff; break;
+                                case 10: a8 = (uint64_t *)(pk + SLIP_PKG_OUT + 8); v8 = lalloc; break;
+                                default: break;
+                            }
+                            if (a8) slip_st_u64(a8, v8);
+                            uint32_t *a4 = (uint32_t *) 0; uint32_t v4 = 0;
+                            switch (lane) {
+                                case 0: a4 = (uint32_t *) &P.row_perm[j]; v4 = (uint32_t) e_pivrow; break;
+                                case 1: a4 = (uint32_t *) &P.row_perm[e_pivpos]; v4 = (uint32_t) intermed2; break;
+                                case 2: a4 = (uint32_t *) &P.pinv[e_pivrow]; v4 = (uint32_t) j; break;
+                                case 3: a4 = (uint32_t *) &P.pinv[intermed2]; v4 = (uint32_t) e_pivpos; break;
+                                case 4: a4 = (uint32_t *) &P.sw_row[j]; v4 = (uint32_t) intermed2; break;
+                                case 5: a4 = (uint32_t *) &P.sw_pos[j]; v4 = (uint32_t) e_pivpos; break;
+                                case 6: a4 = pk + SLIP_PKG_OUT + 1; v4 = (uint32_t) e_pivrow; break;
+                                case 7: a4 = pk + SLIP_PKG_OUT + 2; v4 = (uint32_t) e_pivpos; break;
+                                case 8: a4 = pk + SLIP_PKG_OUT + 3; v4 = (uint32_t)(neg ? -lp_ : lp_); break;
+                                case 9: a4 = pk + SLIP_PKG_OUT + 4; v4 = (uint32_t) pbits; break;
+                                default: break;
+                            }
+                            if (a4) slip_st_u32(a4, v4);
+                        }
+                        if (lane == 0) {
+                            *Mrec = pr;
+                            sv64[SV_LNZ / 2] = nLnz; sv64[SV_LNL / 2] = nLnl; sv64[SV_UNZ / 2] = nUnz; sv64[SV_UNL / 2] = nUnl;
+                            ring_row[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivrow; ring_disp[j & (SLIP_CB_RING - 1)] = (uint32_t) intermed2;
+                            ring_opos[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivpos;
+                            if (j + 1 - sv[C_RING0] > SLIP_CB_RING) sv[C_RING0] = j + 1 - SLIP_CB_RING;
+                            sv[C_LASTPR] = e_pivrow;
+                        }
                     }
                     /* rho[j] for the next column: LDS to LDS */
                     if (lp_ <= wcap) for (int c = lane; c < ((lp_ + 1) & ~1); c += SLIP_WAVE) Ms[c] = src[c];
