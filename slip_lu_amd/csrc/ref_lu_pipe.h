@@ -167,7 +167,9 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
 #define SLIP_PP_WORDS  14
 /* a column's package for the committer (ref_lu_pipe_commit.h), offsets in 32-bit words */
 #define SLIP_PKG_CANDS   16       /* a package lists at most this many candidates ... */
-#define SLIP_PKG_NROWMAX 256      /* ... of a pattern of at most this many rows */
+#ifndef SLIP_PKG_NROWMAX
+#define SLIP_PKG_NROWMAX 256      /* ... of a pattern of at most this many rows (512 measured slower: the committer reads every row) */
+#endif
 #define SLIP_PKG_HDR     0        /* 64-bit {k+1, version}: even = valid, odd = being written or retracted; a column may export again */
 #define SLIP_PKG_STAMP   2
 #define SLIP_PKG_NROWS   3
@@ -177,7 +179,7 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
 #define SLIP_PKG_OUT     32       /* the outcome: a 128-byte line of its own */
 #define SLIP_PKG_CAND    64       /* 6 words per candidate: table index, value (2), aux, position, version */
 #define SLIP_PKG_ROWS    160
-#define SLIP_PKG_WORDS   448
+#define SLIP_PKG_WORDS   704
 
 SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
 SLIP_DEV int slip_abs(int32_t v) { return v < 0 ? -v : v; }

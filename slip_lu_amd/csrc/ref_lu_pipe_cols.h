@@ -871,18 +871,18 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         {
             const int stamp0 = sv[SV_PKGF];
             uint32_t *lg_row = lds + SLIP_LDS_KEYS, *lg_pos = lg_row + SLIP_PAT_CAP;
-            int myr[2] = {-1, -1}, myp[2] = {0, 0};
-            for (int q = 0; q < 2; q++) { const int t = tid + q * T; if (t < nrows) { myr[q] = (int) f_row[t]; myp[q] = (int) f_pos[t]; } }
+            int myr[4] = {-1, -1, -1, -1}, myp[4] = {0, 0, 0, 0};      /* SLIP_PKG_NROWMAX rows over at least 128 threads */
+            for (int q = 0; q < 4; q++) { const int t = tid + q * T; if (t < nrows) { myr[q] = (int) f_row[t]; myp[q] = (int) f_pos[t]; } }
             for (int e0 = stamp0; e0 < k; e0 += SLIP_PAT_CAP) {
                 const int ne = k - e0 < SLIP_PAT_CAP ? k - e0 : SLIP_PAT_CAP;
                 slip_block_sync();
                 for (int e = tid; e < ne; e += T) { lg_row[e] = (uint32_t) slip_ld_i32(&P.sw_row[e0 + e]); lg_pos[e] = (uint32_t) slip_ld_i32(&P.sw_pos[e0 + e]); }
                 slip_block_sync();
-                for (int q = 0; q < 2; q++)
+                for (int q = 0; q < 4; q++)
                     if (myr[q] >= 0) for (int e = 0; e < ne; e++) if ((int) lg_row[e] == myr[q]) myp[q] = (int) lg_pos[e];
             }
             slip_block_sync();
-            for (int q = 0; q < 2; q++) {
+            for (int q = 0; q < 4; q++) {
                 const int t = tid + q * T;
                 if (t < nrows) { slip_atomic_or_u32(&bm[myp[q] >> 5], 1u << (myp[q] & 31)); f_pos[t] = (uint32_t) myp[q]; }
             }

@@ -101,7 +101,7 @@ template <int D> SLIP_DEV void slip_commit_mul(const WR<D> &Mr, uint32_t a0, uin
 
 /* LDS of the committer, words from lds + SLIP_LDS_WORK (the lists, tables and keys of a column worker: 12288 words) */
 #define SLIP_CB          8                  /* columns per batch */
-#define SLIP_CB_RING     1024               /* swaps the committer remembers */
+#define SLIP_CB_RING     512                /* swaps the committer remembers (more than the columns in flight) */
 #define SLIP_CBW         (32 + 6 * SLIP_PKG_CANDS + SLIP_PKG_NROWMAX)      /* one batch column: sums, candidates, rows */
 #define SLIP_CB_SLOTW    262                /* a product of a one-limb value and a pivot of at most 256 digits, whole limbs */
 
@@ -228,11 +228,13 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             if (!hit && lane < ncand && cb[32 + 6 * lane + 5] != hver[i]) hit = 1;
             if (!hit) {
                 const uint32_t *rows = cb + 32 + 6 * SLIP_PKG_CANDS;
-                uint32_t r0 = lane < nrows ? rows[lane] : 0xFFFFFFFFu, r1 = lane + 64 < nrows ? rows[lane + 64] : 0xFFFFFFFFu;
-                uint32_t r2 = lane + 128 < nrows ? rows[lane + 128] : 0xFFFFFFFFu, r3 = lane + 192 < nrows ? rows[lane + 192] : 0xFFFFFFFFu;
+                uint32_t rr[SLIP_PKG_NROWMAX / SLIP_WAVE];
+#pragma unroll
+                for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) rr[q] = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
                 for (int c = stamp; c < kc; c++) {
                     const uint32_t r = ring_row[c & (SLIP_CB_RING - 1)];
-                    if (r0 == r || r1 == r || r2 == r || r3 == r) hit = 1;
+#pragma unroll
+                    for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) if (rr[q] == r) hit = 1;
                 }
             }
             if (slip_ballot(hit) && lane == 0) cb[18] = 1u;
@@ -268,10 +270,11 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 int reject = (int) cb[18];
                 if (!reject && i > 0) {
                     /* ... and against the pivots of this batch */
-                    const uint32_t r0 = lane < nrows ? rows[lane] : 0xFFFFFFFFu, r1 = lane + 64 < nrows ? rows[lane + 64] : 0xFFFFFFFFu;
-                    const uint32_t r2 = lane + 128 < nrows ? rows[lane + 128] : 0xFFFFFFFFu, r3 = lane + 192 < nrows ? rows[lane + 192] : 0xFFFFFFFFu;
                     int hit = 0;
-                    for (int c = kc; c < j; c++) { const uint32_t r = ring_row[c & (SLIP_CB_RING - 1)]; if (r0 == r || r1 == r || r2 == r || r3 == r) hit = 1; }
+                    for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) {
+                        const uint32_t rq = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
+                        for (int c = kc; c < j; c++) if (ring_row[c & (SLIP_CB_RING - 1)] == rq) hit = 1;
+                    }
                     if (slip_ballot(hit)) reject = 1;
                 }
                 if (!reject) {

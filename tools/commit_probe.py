@@ -6,13 +6,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_case
 import slip_lu_amd as sl
+LIB = os.environ.get("SLIP_PROBE_LIB")
+FLAGS = [int(x) for x in os.environ.get("SLIP_PROBE_FLAGS", "0,4,2").split(",")]
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 waves = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 for name in sys.argv[1].split(","):
     entry, fix = load_case(name)
-    for flags in (0, 4, 2):
+    for flags in FLAGS:
         f = sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], pivot=entry["pivot"],
-                             tol=entry["tol"], limb_cap=entry["cap"], workers=workers, waves=waves, debug_flags=flags)
+                             tol=entry["tol"], limb_cap=entry["cap"], workers=workers, waves=waves, debug_flags=flags, **({"lib_path": LIB} if LIB else {}))
         f.run(entry["kmax"], check=False); i0 = f.info(); f.reset(); rc = f.run(entry["kmax"], check=False)
         i = f.info()
         print(f"{name}: first run launches {i0['launches']} xcap {i0['xcap_digits']} ms {i0['kernel_ms']:.2f}; second: launches {i['launches']} xcap {i['xcap_digits']}; flags {flags} rc {rc} K {i['K']} short_commits {i['short_commits']} by committer {i['committer_commits']} farm jobs {i['farm_jobs']} helped items {i['farm_items']} workers {i['workers']} kernel_ms {i['kernel_ms']:.3f} "
