@@ -654,7 +654,7 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
     {
         const SlipParams P = f->P; SlipState *ds = f->ds;
         const int fast = f->bitmap_in_lds && f->scratch_in_lds;
-        const size_t words = (size_t) f->lds_words + 64;
+        const size_t words = (((size_t) f->lds_words + 64) + 3) & ~(size_t) 3;      /* every emulated workgroup's LDS 16-byte aligned, as on the device */
         uint32_t *lds_all = (uint32_t *) calloc((size_t) W * words, 4);
         if (!lds_all) return SLIP_HIP_OUT_OF_MEMORY;
         emu::set_seed(slip_emu_seed);
@@ -854,7 +854,7 @@ static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, int32_t *rhs
     {
         const SlipParams P = f->P; SlipState *ds = f->ds;
         const int fast = f->bitmap_in_lds && f->scratch_in_lds;
-        const size_t words = (size_t) f->lds_words + 64;
+        const size_t words = (((size_t) f->lds_words + 64) + 3) & ~(size_t) 3;      /* every emulated workgroup's LDS 16-byte aligned, as on the device */
         uint32_t *lds_all = (uint32_t *) calloc((size_t) W * words, 4);
         if (!lds_all) return SLIP_HIP_OUT_OF_MEMORY;
         emu::set_seed(slip_emu_seed);

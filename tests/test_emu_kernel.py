@@ -62,6 +62,32 @@ def test_emulated_workers_help_with_update_queues(emu_farm_lib, name, waves, wor
         check_against_golden(entry, fix, res)
 
 
+def test_emulated_kernel_under_sanitizers():
+    """the kernel source (committer, packages, helpers included) under AddressSanitizer + UBSan on the CPU: a subprocess with
+    libasan preloaded runs small cases against the goldens; any report aborts it (GPU sanitizers are not available)"""
+    import sys
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu_dir, "libslip_emu_san.so"])
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not found")
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import load_case, check_against_golden\n"
+        "import slip_lu_amd as sl\n"
+        "for name, w, wv in [('test_mat', 3, 2), ('gen_n40', 4, 2), ('test_mat_p4tol', 5, 1)]:\n"
+        "    entry, fix = load_case(name)\n"
+        "    res = sl.factorize(entry['n'], fix['Ap'], fix['Ai'], fix['Alen'], fix['Alimbs'], fix['q'], pivot=entry['pivot'], tol=entry['tol'],\n"
+        "                       kmax=entry['kmax'], limb_cap=entry['cap'], waves=wv, workers=w, lib_path=%r)\n"
+        "    check_against_golden(entry, fix, res)\n"
+        "print('sanitized run ok')\n") % (ROOT, os.path.join(ROOT, "tests"), os.path.join(emu_dir, "libslip_emu_san.so"))
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "sanitized run ok" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
+
+
 @pytest.mark.parametrize("name,waves,workers,nrhs", [("solve_test_mat", 2, 1, 1), ("solve_gen_n40", 2, 2, 2),
                                                      ("solve_gen_n40", 1, 3, 3)])
 def test_emulated_solve_matches_reference(emu_lib, name, waves, workers, nrhs):
