@@ -145,6 +145,16 @@ int slip_hip_factor_rescale(slip_hip_factor *f, const int32_t *slen, const uint6
 
 void slip_hip_factor_destroy(slip_hip_factor *f);
 
+/* Triplet files <-> limb slabs, host only.  read: what SLIP_tripread + SLIP_build_sparse_trip_mpz
+ * produce (SLIP_LU/Demo/demos.c:245-331, SLIP_LU/Source/slip_trip_to_mat.c:23-69: "m n nz" then nz lines "i j value",
+ * indices 1-based unless the first entry holds a 0, columns by counting sort in file order, duplicates kept), as the
+ * arrays slip_hip_factor_create takes; they are malloc'ed, release with slip_hip_free.  Malformed input is
+ * SLIP_HIP_INCORRECT_INPUT as in the reference.  write: the inverse (1-based, decimal), readable by either. */
+int slip_hip_read_triplet(const char *path, int32_t *n_out, int64_t **Ap, int32_t **Ai, int32_t **Alen, uint64_t **Alimbs,
+                          int64_t *nlimbs_out);
+int slip_hip_write_triplet(const char *path, int32_t n, const int64_t *Ap, const int32_t *Ai, const int32_t *Alen,
+                           const uint64_t *Alimbs);
+
 /* Deterministic synthetic CSC generator of the benchmark configs
  * (slip_matgen.h): arrays are malloc'ed, release with slip_hip_free. */
 int slip_hip_matgen(int32_t n, double density, int32_t bits, uint64_t seed,

@@ -5,4 +5,4 @@ and the GMP-typed drop-in shim (csrc/libslip_lu_hip.so); this package is the thi
 ctypes layer the tests and bench.py use.
 """
 from . import api  # noqa: F401
-from .api import Factorization, SlipError, factorize, ints_to_slab, matgen  # noqa: F401
+from .api import Factorization, SlipError, factorize, ints_to_slab, matgen, read_triplet, write_triplet  # noqa: F401

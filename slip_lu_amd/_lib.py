@@ -33,7 +33,7 @@ EXPORTS = ("slip_hip_default_options", "slip_hip_device_count", "slip_hip_factor
            "slip_hip_factor_download", "slip_hip_factor_destroy", "slip_hip_matgen",
            "slip_hip_free", "slip_hip_wave_op_test", "slip_hip_version",
            "slip_hip_factor_phase_cycles", "slip_hip_factor_solve", "slip_hip_factor_solve_ms",
-           "slip_hip_factor_from_factors", "slip_hip_factor_rescale")
+           "slip_hip_factor_from_factors", "slip_hip_factor_rescale", "slip_hip_read_triplet", "slip_hip_write_triplet")
 
 _libs = {}
 
@@ -65,6 +65,8 @@ def load(path=None):
     lib.slip_hip_factor_destroy.restype = None
     lib.slip_hip_matgen.argtypes = [C.c_int32, C.c_double, C.c_int32, C.c_uint64,
                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.slip_hip_read_triplet.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
+    lib.slip_hip_write_triplet.argtypes = [C.c_char_p, C.c_int32, vp, vp, vp, vp]
     lib.slip_hip_free.argtypes = [vp]
     lib.slip_hip_free.restype = None
     lib.slip_hip_wave_op_test.argtypes = [C.c_int32] * 5 + [vp, vp, vp]

@@ -6,6 +6,7 @@ step (data to this module), `Factorization.run` is SLIP_LU_factorize.
 All arithmetic happens in the HIP library; this file only marshals arrays.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -43,6 +44,38 @@ def matgen(n, density, bits, seed, lib_path=None):
     for p in (pAp, pAi, pAx):
         lib.slip_hip_free(p)
     return Ap, Ai, Ax
+
+
+def read_triplet(path, lib_path=None):
+    """A triplet file (SLIP_tripread's format, SLIP_LU/Demo/demos.c:245-331) -> n, Ap, Ai, Alen, Alimbs: the CSC limb slabs
+    SLIP_build_sparse_trip_mpz would hold (slip_trip_to_mat.c:23-69), ready for Factorization()."""
+    lib = _lib.load(lib_path)
+    n, nl = C.c_int32(), C.c_int64()
+    pAp, pAi, pAlen, pAl = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    rc = lib.slip_hip_read_triplet(os.fsencode(path), C.byref(n), C.byref(pAp), C.byref(pAi), C.byref(pAlen), C.byref(pAl), C.byref(nl))
+    if rc:
+        raise SlipError(rc, "slip_hip_read_triplet")
+    n = n.value
+    Ap = np.ctypeslib.as_array(C.cast(pAp, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+    nnz = int(Ap[n])
+    Ai = np.ctypeslib.as_array(C.cast(pAi, C.POINTER(C.c_int32)), shape=(nnz,)).copy()
+    Alen = np.ctypeslib.as_array(C.cast(pAlen, C.POINTER(C.c_int32)), shape=(nnz,)).copy()
+    Al = np.ctypeslib.as_array(C.cast(pAl, C.POINTER(C.c_uint64)), shape=(max(nl.value, 1),)).copy()[:nl.value]
+    for p in (pAp, pAi, pAlen, pAl):
+        lib.slip_hip_free(p)
+    return n, Ap, Ai, Alen, Al
+
+
+def write_triplet(path, n, Ap, Ai, Alen, Alimbs, lib_path=None):
+    """CSC limb slabs -> a triplet file (1-based, decimal) that SLIP_tripread and read_triplet accept."""
+    lib = _lib.load(lib_path)
+    Ap = np.ascontiguousarray(Ap, np.int64); Ai = np.ascontiguousarray(Ai, np.int32)
+    Alen = np.ascontiguousarray(Alen, np.int32); Al = np.ascontiguousarray(Alimbs, np.uint64)
+    if Al.size == 0:
+        Al = np.zeros(1, np.uint64)
+    rc = lib.slip_hip_write_triplet(os.fsencode(path), int(n), Ap.ctypes.data, Ai.ctypes.data, Alen.ctypes.data, Al.ctypes.data)
+    if rc:
+        raise SlipError(rc, "slip_hip_write_triplet")
 
 
 class Factorization:

@@ -1,3 +1,4 @@
+#include <vector>
 /* slip_hip.hip -- libslip_hip.so: kernels' entry points and the host side of the
  * C ABI declared in include/slip_hip.h.
  *
@@ -309,6 +310,129 @@ extern "C" int slip_hip_device_count(void)
 }
 
 extern "C" void slip_hip_free(void *p) { free(p); }
+
+/* ---- triplet files into limb slabs and back, host only, no GMP ----
+ * The reference reads "m n nz" and nz lines "i j value" with gmp_fscanf %Zd (SLIP_LU/Demo/demos.c:245-331: indices are
+ * 1-based unless the FIRST entry holds a 0) and builds the CSC by a counting sort on the columns that keeps the file
+ * order inside a column and keeps duplicates (SLIP_LU/Source/slip_trip_to_mat.c:23-69).  Here the decimal strings go
+ * straight into 64-bit limbs (base-10^18 chunks multiplied in), one pass over the file, one allocation per array. */
+static int trip_parse_value(const char *s, const char *e, std::vector<uint64_t> &mag, int *neg)
+{
+    *neg = 0; mag.clear();
+    if (s < e && (*s == '-' || *s == '+')) { *neg = *s == '-'; s++; }
+    if (s >= e) return -1;
+    for (const char *p = s; p < e; p++) if (*p < '0' || *p > '9') return -1;
+    while (s < e) {
+        const int take = (int)((e - s) % 18 ? (e - s) % 18 : 18);
+        uint64_t chunk = 0, scale = 1;
+        for (int q = 0; q < take; q++) { chunk = chunk * 10u + (uint64_t)(s[q] - '0'); scale *= 10u; }
+        s += take;
+        /* mag = mag * scale + chunk */
+        unsigned __int128 carry = chunk;
+        for (size_t l = 0; l < mag.size(); l++) { carry += (unsigned __int128) mag[l] * scale; mag[l] = (uint64_t) carry; carry >>= 64; }
+        if (carry) mag.push_back((uint64_t) carry);
+    }
+    while (!mag.empty() && mag.back() == 0) mag.pop_back();
+    if (mag.empty()) *neg = 0;
+    return 0;
+}
+
+extern "C" int slip_hip_read_triplet(const char *path, int32_t *n_out, int64_t **Ap_out, int32_t **Ai_out, int32_t **Alen_out,
+                                     uint64_t **Alimbs_out, int64_t *nlimbs_out)
+{
+    if (!path || !n_out || !Ap_out || !Ai_out || !Alen_out || !Alimbs_out) return SLIP_HIP_INCORRECT_INPUT;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return SLIP_HIP_INCORRECT_INPUT;
+    std::vector<char> buf;
+    { char tmp[1 << 16]; size_t r; while ((r = fread(tmp, 1, sizeof tmp, fp)) > 0) buf.insert(buf.end(), tmp, tmp + r); }
+    fclose(fp);
+    buf.push_back('\0');
+    const char *p = buf.data(), *end = buf.data() + buf.size() - 1;
+    auto token = [&](const char **ts, const char **te) -> int {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+        if (p >= end) return -1;
+        *ts = p;
+        while (p < end && !(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+        *te = p;
+        return 0;
+    };
+    auto int_token = [&](long long *v) -> int {
+        const char *ts, *te;
+        if (token(&ts, &te)) return -1;
+        char *ep = NULL; const long long x = strtoll(ts, &ep, 10);
+        if (ep != te) return -1;
+        *v = x; return 0;
+    };
+    long long m, n, nz;
+    if (int_token(&m) || int_token(&n) || int_token(&nz)) return SLIP_HIP_INCORRECT_INPUT;
+    if (n <= 0 || m != n || nz <= 0 || n > INT32_MAX || nz > INT32_MAX) return SLIP_HIP_INCORRECT_INPUT;
+    std::vector<int32_t> I((size_t) nz), J((size_t) nz), L((size_t) nz);
+    std::vector<int64_t> off((size_t) nz + 1);
+    std::vector<uint64_t> limbs, mag;
+    limbs.reserve((size_t) nz);
+    long long dec = 0;
+    for (long long t = 0; t < nz; t++) {
+        long long i, j; const char *ts, *te; int neg;
+        if (int_token(&i) || int_token(&j) || token(&ts, &te) || trip_parse_value(ts, te, mag, &neg)) return SLIP_HIP_INCORRECT_INPUT;
+        if (t == 0) dec = (i < j ? i : j) == 0 ? 0 : 1;           /* demos.c:290-299 */
+        i -= dec; j -= dec;
+        if (i < 0 || j < 0 || i >= n || j >= n) return SLIP_HIP_INCORRECT_INPUT;
+        I[(size_t) t] = (int32_t) i; J[(size_t) t] = (int32_t) j;
+        off[(size_t) t] = (int64_t) limbs.size();
+        L[(size_t) t] = neg ? -(int32_t) mag.size() : (int32_t) mag.size();
+        limbs.insert(limbs.end(), mag.begin(), mag.end());
+    }
+    off[(size_t) nz] = (int64_t) limbs.size();
+    /* counting sort on the columns, file order kept inside a column (slip_trip_to_mat.c:47-64) */
+    int64_t *Ap = (int64_t *) calloc((size_t) n + 1, sizeof(int64_t));
+    int32_t *Ai = (int32_t *) malloc((size_t) nz * sizeof(int32_t)), *Alen = (int32_t *) malloc((size_t) nz * sizeof(int32_t));
+    uint64_t *Al = (uint64_t *) malloc((limbs.size() ? limbs.size() : 1) * sizeof(uint64_t));
+    if (!Ap || !Ai || !Alen || !Al) { free(Ap); free(Ai); free(Alen); free(Al); return SLIP_HIP_OUT_OF_MEMORY; }
+    for (long long t = 0; t < nz; t++) Ap[J[(size_t) t] + 1]++;
+    for (long long c = 0; c < n; c++) Ap[c + 1] += Ap[c];
+    std::vector<int64_t> w(Ap, Ap + n), src((size_t) nz);
+    for (long long t = 0; t < nz; t++) { const int64_t q = w[(size_t) J[(size_t) t]]++; Ai[q] = I[(size_t) t]; Alen[q] = L[(size_t) t]; src[(size_t) q] = t; }
+    int64_t o = 0;
+    for (long long q = 0; q < nz; q++) {
+        const int64_t t = src[(size_t) q], l = off[(size_t) t + 1] - off[(size_t) t];
+        if (l) memcpy(Al + o, limbs.data() + off[(size_t) t], (size_t) l * 8);
+        o += l;
+    }
+    *n_out = (int32_t) n; *Ap_out = Ap; *Ai_out = Ai; *Alen_out = Alen; *Alimbs_out = Al;
+    if (nlimbs_out) *nlimbs_out = o;
+    return SLIP_HIP_OK;
+}
+
+/* the inverse: CSC limb slabs to a triplet file the reference's SLIP_tripread accepts (1-based, decimal) */
+extern "C" int slip_hip_write_triplet(const char *path, int32_t n, const int64_t *Ap, const int32_t *Ai, const int32_t *Alen, const uint64_t *Alimbs)
+{
+    if (!path || n <= 0 || !Ap || !Ai || !Alen || !Alimbs) return SLIP_HIP_INCORRECT_INPUT;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return SLIP_HIP_INCORRECT_INPUT;
+    fprintf(fp, "%d %d %lld\n", n, n, (long long) Ap[n]);
+    int64_t o = 0;
+    std::vector<uint64_t> mag; std::vector<uint64_t> chunks;
+    for (int32_t c = 0; c < n; c++)
+        for (int64_t q = Ap[c]; q < Ap[c + 1]; q++) {
+            const int l = Alen[q] < 0 ? -Alen[q] : Alen[q];
+            mag.assign(Alimbs + o, Alimbs + o + l); o += l;
+            chunks.clear();
+            while (!mag.empty()) {                                   /* divide by 10^18, collect the remainders */
+                unsigned __int128 rem = 0;
+                for (size_t k = mag.size(); k-- > 0;) { rem = (rem << 64) | mag[k]; mag[k] = (uint64_t)(rem / 1000000000000000000ull); rem %= 1000000000000000000ull; }
+                chunks.push_back((uint64_t) rem);
+                while (!mag.empty() && mag.back() == 0) mag.pop_back();
+            }
+            fprintf(fp, "%d %d %s", Ai[q] + 1, c + 1, Alen[q] < 0 ? "-" : "");
+            if (chunks.empty()) fprintf(fp, "0");
+            else {
+                fprintf(fp, "%llu", (unsigned long long) chunks.back());
+                for (size_t k = chunks.size() - 1; k-- > 0;) fprintf(fp, "%018llu", (unsigned long long) chunks[k]);
+            }
+            fprintf(fp, "\n");
+        }
+    return fclose(fp) == 0 ? SLIP_HIP_OK : SLIP_HIP_DEVICE_ERROR;
+}
 
 extern "C" int slip_hip_matgen(int32_t n, double density, int32_t bits, uint64_t seed,
                                int64_t **Ap, int32_t **Ai, int64_t **Ax)
@@ -1145,6 +1269,21 @@ extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)
 
 /* entry records -> signed 64-bit limb counts, and the limbs gathered entry by entry into the back-to-back layout
  * of the ABI (slots of rows multiplied straight into the slab may leave unused limbs behind them) */
+/* entries' limbs, scattered over a slab with gaps (an early commit reserves a column's region from bounds), packed back
+ * to back on the device: one wavefront per entry, coalesced; the host then copies exactly the limbs it was promised */
+#ifndef SLIP_EMULATE
+__global__ void __launch_bounds__(256) slip_gather_kernel(const SlipEnt *ent, const uint64_t *limbs, const int64_t *ooff, uint64_t *out, int64_t nz)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t) gridDim.x * blockDim.x) >> 6;
+    for (int64_t t = wave; t < nz; t += nwaves) {
+        const int64_t l = ooff[t + 1] - ooff[t];
+        const uint64_t *src = limbs + ent[t].off; uint64_t *dst = out + ooff[t];
+        for (int64_t c = lane; c < l; c += 64) dst[c] = src[c];
+    }
+}
+#endif
+
 static int fetch_factor(int32_t *len_out, uint64_t *limbs_out, const SlipEnt *dev_ent, const uint64_t *dev_limbs, int64_t nz, int64_t nl_alloc)
 {
     if (nz <= 0) return 0;
@@ -1159,6 +1298,26 @@ static int fetch_factor(int32_t *len_out, uint64_t *limbs_out, const SlipEnt *de
         }
     int rc = 0;
     if (limbs_out && nl_alloc > 0) {
+#ifndef SLIP_EMULATE
+        /* one pass on the device, then one copy of exactly the packed limbs */
+        int64_t *ooff = (int64_t *) malloc(((size_t) nz + 1) * 8), *d_ooff = NULL; uint64_t *d_out = NULL;
+        if (!ooff) { free(ent); return SLIP_HIP_OUT_OF_MEMORY; }
+        ooff[0] = 0;
+        for (int64_t t = 0; t < nz; t++) { const int32_t d = ent[t].len; ooff[t + 1] = ooff[t] + (((d < 0 ? -d : d) + 1) >> 1); }
+        const int64_t total = ooff[nz];
+        if (total > 0) {
+            if (dev_alloc(&d_ooff, nz + 1) || dev_alloc(&d_out, total)) rc = SLIP_HIP_OUT_OF_MEMORY;
+            else if (hipMemcpy(d_ooff, ooff, ((size_t) nz + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+            else {
+                int64_t blocks = (nz + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+                hipLaunchKernelGGL(slip_gather_kernel, dim3((unsigned) blocks), dim3(256), 0, 0, dev_ent, dev_limbs, d_ooff, d_out, nz);
+                if (hipGetLastError() != hipSuccess || hipMemcpy(limbs_out, d_out, (size_t) total * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+            }
+            if (d_ooff) hipFree(d_ooff);
+            if (d_out) hipFree(d_out);
+        }
+        free(ooff);
+#else
         uint64_t *raw = (uint64_t *) malloc((size_t) nl_alloc * 8);
         if (!raw) rc = SLIP_HIP_OUT_OF_MEMORY;
         else if (hipMemcpy(raw, dev_limbs, (size_t) nl_alloc * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
@@ -1172,6 +1331,7 @@ static int fetch_factor(int32_t *len_out, uint64_t *limbs_out, const SlipEnt *de
             }
         }
         free(raw);
+#endif
     }
     free(ent);
     return rc;

@@ -22,6 +22,8 @@
 #include "../../include/slip_hip.h"
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <stdio.h>
 
 extern void *SLIP_calloc(size_t n, size_t size) __attribute__((weak));
 
@@ -79,6 +81,9 @@ SLIP_info SLIP_hip_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, 
     slip_hip_options opt;
     int rc;
 
+    /* SLIP_HIP_SHIM_TIMING=1: where the call spends its time, one line on stderr (conversions are one pass each way) */
+    struct timespec t0_, t1_, t2_, t3_, t4_;
+    clock_gettime(CLOCK_MONOTONIC, &t0_);
     /* ---- A: mpz_t -> limb slab ---- */
     int64_t nl = 0;
     for (int64_t t = 0; t < annz; t++) nl += (int64_t) mpz_size(A->x[t]);
@@ -97,6 +102,7 @@ SLIP_info SLIP_hip_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, 
         }
     }
 
+    clock_gettime(CLOCK_MONOTONIC, &t1_);
     /* ---- factorise on the GPU ---- */
     slip_hip_default_options(&opt);
     opt.pivot = (int32_t) option->pivot;
@@ -109,6 +115,7 @@ SLIP_info SLIP_hip_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, 
             : rc == SLIP_HIP_INCORRECT_INPUT ? SLIP_INCORRECT_INPUT : SLIP_OUT_OF_MEMORY;
         goto done;
     }
+    clock_gettime(CLOCK_MONOTONIC, &t2_);
     slip_hip_factor_info(f, &info);
     if (info.lnz > INT32_MAX || info.unz > INT32_MAX) goto done;      /* int32 CSC of the reference */
     Lp = (int64_t *) malloc(((size_t) n + 1) * 8); Up = (int64_t *) malloc(((size_t) n + 1) * 8);
@@ -125,6 +132,7 @@ SLIP_info SLIP_hip_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, 
             goto done;
     }
 
+    clock_gettime(CLOCK_MONOTONIC, &t3_);
     /* ---- hand the results over the way the reference does ---- */
     ret = build_factor(L, n, info.lnz, Lp, Li, Llen, Llimbs, pinv);
     if (ret == SLIP_OK) ret = build_factor(U, n, info.unz, Up, Ui, Ulen, Ulimbs, pinv);
@@ -134,6 +142,15 @@ SLIP_info SLIP_hip_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, 
             set_from_limbs(rhos[k], rholen[k], rholimbs + o);
             o += rholen[k] < 0 ? -rholen[k] : rholen[k];
         }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t4_);
+    if (getenv("SLIP_HIP_SHIM_TIMING")) {
+#define MS_(a, b) (((b).tv_sec - (a).tv_sec) * 1e3 + ((b).tv_nsec - (a).tv_nsec) * 1e-6)
+        fprintf(stderr, "slip_lu_hip timing: A to slabs %.3f ms, upload+factorise %.3f ms (kernel %.3f ms), download %.3f ms, "
+                        "L/U/rhos to mpz %.3f ms (%lld + %lld entries, %lld limbs)\n",
+                MS_(t0_, t1_), MS_(t1_, t2_), info.kernel_ms, MS_(t2_, t3_), MS_(t3_, t4_),
+                (long long) info.lnz, (long long) info.unz, (long long)(info.l_limbs + info.u_limbs));
+#undef MS_
     }
 done:
     if (f) slip_hip_factor_destroy(f);

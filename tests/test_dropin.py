@@ -70,3 +70,28 @@ def test_dropin_error_paths_match_reference():
     got, want = run_both(["--errors"])
     assert "singular=-2" in got and "null_all factorize=-3 solve=-3" in got
     assert got == want
+
+
+def test_dropin_on_rl5934_with_conversion_times(tmp_path, record_property):
+    """an LP basis of the reference's benchmark set through the whole drop-in path: the triplet file is written by the
+    product's own writer (slip_hip_write_triplet) and read by the REFERENCE's SLIP_tripread inside both binaries; the shim
+    reports what its one-pass conversions cost next to the device time (SLIP_HIP_SHIM_TIMING)"""
+    import re
+    import slip_lu_amd as sl
+    entry, fix = load_case("rl5934")
+    trip = str(tmp_path / "A.txt")
+    sl.write_triplet(trip, entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"])
+    assert all(np.array_equal(np.asarray(a).astype(np.uint64), np.asarray(b).astype(np.uint64))
+               for a, b in zip(sl.read_triplet(trip)[1:], (fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"])))
+    hip, ref = binaries()
+    args = [trip, "3", "1"]
+    out_ref = subprocess.run([ref] + args, capture_output=True, text=True, timeout=900)
+    out_hip = subprocess.run([hip] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, SLIP_HIP_SHIM_TIMING="1"))
+    assert out_ref.returncode == 0 and out_hip.returncode == 0, out_hip.stdout + out_hip.stderr
+    assert out_hip.stdout.startswith("check=0 check_corrupt=-4 ") and out_hip.stdout == out_ref.stdout
+    m = re.search(r"slip_lu_hip timing: A to slabs ([0-9.]+) ms, upload\+factorise ([0-9.]+) ms \(kernel ([0-9.]+) ms\), download ([0-9.]+) ms, "
+                  r"L/U/rhos to mpz ([0-9.]+) ms", out_hip.stderr)
+    assert m, out_hip.stderr
+    print("\nrl5934 drop-in:", m.group(0))
+    for key, val in zip(("a_to_slabs_ms", "upload_factorise_ms", "kernel_ms", "download_ms", "to_mpz_ms"), m.groups()):
+        record_property(key, float(val))

@@ -67,7 +67,7 @@ def test_emulated_kernel_under_sanitizers():
     libasan preloaded runs small cases against the goldens; any report aborts it (GPU sanitizers are not available)"""
     import sys
     emu_dir = os.path.join(ROOT, "tests", "emu")
-    subprocess.check_call(["make", "-s", "-C", emu_dir, "libslip_emu_san.so"])
+    subprocess.check_call(["make", "-s", "-C", emu_dir, "-f", "sanitize.mk", "libslip_emu_san.so"])
     libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
     if not os.path.isabs(libasan) or not os.path.exists(libasan):
         pytest.skip("libasan not found")

@@ -269,3 +269,16 @@ def test_gpu_repeated_runs_under_load_are_identical():
     finally:
         for f in handles:
             f.close()
+
+
+@pytest.mark.gpu
+def test_gpu_triplet_file_to_factors():
+    """a Demo/SLIPLU.c-shaped path without the reference's reader: the triplet file goes through slip_hip_read_triplet into
+    limb slabs, through the factorisation, and the factors equal the reference's golden record"""
+    import os
+    import slip_lu_amd as sl
+    from conftest import GOLDEN
+    entry, fix = load_case("test_mat")
+    n, Ap, Ai, Alen, Al = sl.read_triplet(os.path.join(GOLDEN, "test_mat_triplet.txt"))
+    res = sl.factorize(n, Ap, Ai, Alen, Al, fix["q"], pivot=entry["pivot"], tol=entry["tol"], kmax=entry["kmax"], limb_cap=entry["cap"])
+    check_against_golden(entry, fix, res)
