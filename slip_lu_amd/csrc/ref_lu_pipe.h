@@ -78,7 +78,8 @@ typedef struct SlipState {
     int32_t F2; int32_t padF2[31];                  /* ready frontier: columns < F2 have published their L entries (stage 2) */
     int32_t ticket; int32_t padT[31];               /* next column ticket (monotonic across launches)                    */
     int32_t exited, padE[31];                       /* workers that have left the launch (the last one writes the summary) */
-    int32_t farm_hint, padH[31];                    /* worker + 1 of a worker whose update queue is open to helpers (last writer wins; a hint) */
+    int32_t farm_hint, padH[31];
+    int32_t dbg_who, dbg_k, dbg_a, dbg_b;           /* which wait ran into the spin limit (diagnostic) */                    /* worker + 1 of a worker whose update queue is open to helpers (last writer wins; a hint) */
     int32_t k_next, status, status_k, solve_next;
     int64_t Lnz, Lnl, Unz, Unl;                     /* mirrors of Lp/Lo/Up/Uo at the frontier (written at kernel end)     */
     int64_t Lnl_exact, Unl_exact;                   /* limbs actually stored                                             */
@@ -176,7 +177,9 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
 #define SLIP_PKG_SUMS    4        /* SLIP_PP_WORDS words */
 #define SLIP_PKG_STAMP0  18
 #define SLIP_PKG_VER     19       /* the version the sums belong to (every candidate record carries it too) */
-#define SLIP_PKG_OUT     32       /* the outcome: a 128-byte line of its own */
+#define SLIP_PKG_WORKER  20       /* the exporting worker: its verdict goes to ITS mailbox (the slot may be reused by column k + nworkers before the worker has read it) */
+#define SLIP_MBOX_WORDS  32       /* a worker's mailbox, behind the package slots: the outcome words */
+#define SLIP_PKG_OUT     0        /* the outcome words, as offsets into the exporting worker's MAILBOX (P.pkg + nworkers * SLIP_PKG_WORDS + worker * SLIP_MBOX_WORDS) */
 #define SLIP_PKG_CAND    64       /* 6 words per candidate: table index, value (2), aux, position, version */
 #define SLIP_PKG_ROWS    160
 #define SLIP_PKG_WORDS   704
@@ -1166,7 +1169,7 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
                 slip_agent_add_i32((int32_t *) jb, -1);                          /* closed: nobody new gets in */
                 if (slip_ld_i32(&P.st->farm_hint) == P.worker + 1) slip_st_i32(&P.st->farm_hint, 0);
                 unsigned long long spins = 0;
-                while ((slip_agent_add_i32((int32_t *) jb, 0) >> 8) != 0) { slip_sleep_short(); if (++spins > SLIP_SPIN_LIMIT) { sv[SV_ERR] = SLIPDEV_INTERNAL; break; } }
+                while ((slip_agent_add_i32((int32_t *) jb, 0) >> 8) != 0) { slip_sleep_short(); if (++spins > SLIP_SPIN_LIMIT) { sv[SV_ERR] = SLIPDEV_INTERNAL; P.st->dbg_who = 5; P.st->dbg_k = sv[SV_K]; P.st->dbg_a = slip_agent_add_i32((int32_t *) jb, 0); break; } }
                 const int he = (int) slip_ld_u32(jb + 11);
                 if (he) sv[SV_ERR] = he;
                 slip_agent_release(); slip_agent_acquire();                      /* the helpers' results, next to what this CU wrote */

@@ -39,7 +39,7 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, i
             const int dist = k - F;
             if (dist <= 1) slip_sleep_short();
             else { const int reps = dist < 32 ? dist : 32; for (int q = 0; q < reps; q++) slip_sleep(); }
-            if (++spins > SLIP_SPIN_LIMIT) { slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
+            if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 1; st->dbg_k = k; st->dbg_a = need; st->dbg_b = F; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
         }
         sv[SV_TMP2] = res;
     }
@@ -78,7 +78,7 @@ SLIP_DEV int slip_wait_ready(const SlipParams &P, SlipState *st, uint32_t *lds, 
             if (f2 >= need || slip_agent_add_i32(&P.Lready[need - 1], 0) != 0) { res = f2; break; }
             if ((int)(slip_ld_i64(&st->stop) & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             slip_sleep_short();
-            if (++spins > SLIP_SPIN_LIMIT) { slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
+            if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 2; st->dbg_k = sv[SV_K]; st->dbg_a = need; st->dbg_b = f2; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
         }
         sv[SV_TMP2] = res;
     }
@@ -630,7 +630,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     const int packaged = P.committer && try_early && sv[SV_PKGX];
     slip_block_sync();                                   /* (thread 0 clears the flag below) */
     if (packaged) for (;;) {
-        const uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
+        const uint32_t *pk = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;      /* this worker's mailbox */
         if (tid == 0) {
             int res; unsigned long long spins = 0;
             for (;;) {
@@ -641,7 +641,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
                 { const int h = slip_farm_peek(P, st); if (h) { res = -1 - h; break; } }
                 slip_sleep_short();
-                if (++spins > SLIP_SPIN_LIMIT) { slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
+                if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 3; st->dbg_k = k; st->dbg_a = v; st->dbg_b = mine_; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
             }
             sv[SV_TMP2] = res;
             if (res == 0) sv[SV_PKGX] = 0;               /* rejected: this worker commits the column itself */
@@ -862,8 +862,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     /* ---- the short commit chain (see slip_prepass) ---- */
     int ec = -1;                                 /* 0: committed early; > 0: a status; -1: the full pass below decides */
     if (adopted) {
-        /* the committer has published this column's pivot: take over the outcome and the position snapshot it took */
-        const uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
+        /* the committer has published this column's pivot: take over the outcome from this worker's mailbox */
+        const uint32_t *pk = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;
         if (BMs) { const dig_t *Mg = slip_piv_digits(P, M); for (int c = tid; c < lm; c += T) Ms[c] = slip_ld_u32(Mg + c); }
         /* the position snapshot (pinv as the reference has it at column k): the value the pre-pass read at frontier stamp0, or
          * where the LAST swap in [stamp0, k) that displaced the row put it (positions of non-pivotal rows only ever grow, and a

@@ -54,7 +54,8 @@ SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *ld
     if (tid < SLIP_PP_WORDS) slip_st_u32(pk + SLIP_PKG_SUMS + tid, (uint32_t) sv[SV_PP + tid]);
     if (tid == SLIP_PP_WORDS) {
         slip_st_u32(pk + SLIP_PKG_STAMP, (uint32_t) Fl); slip_st_u32(pk + SLIP_PKG_STAMP0, (uint32_t) Fl);
-        slip_st_u32(pk + SLIP_PKG_NROWS, (uint32_t) nrows); slip_st_u32(pk + SLIP_PKG_VER, ver); slip_st_u32(pk + SLIP_PKG_OUT, 0u);
+        slip_st_u32(pk + SLIP_PKG_NROWS, (uint32_t) nrows); slip_st_u32(pk + SLIP_PKG_VER, ver); slip_st_u32(pk + SLIP_PKG_WORKER, (uint32_t) P.worker);
+        slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS + SLIP_PKG_OUT, 0u);
     }
     slip_vm_drain();
     slip_block_sync();
@@ -178,7 +179,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 const int nb = slip_ctz64(~slip_ballot(rdy));
                 if (nb >= 1) { go = nb < SLIP_CB ? nb : SLIP_CB; break; }
                 slip_sleep_short();
-                if (++spins > SLIP_SPIN_LIMIT) { if (lane == 0) slip_raise_stop(st, 0, SLIPDEV_INTERNAL); go = 0; break; }
+                if (++spins > SLIP_SPIN_LIMIT) { if (lane == 0) { st->dbg_who = 4; st->dbg_k = kc; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); } go = 0; break; }
             }
             if (lane == 0) sv[C_GO] = go;
         }
@@ -200,6 +201,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             else if (lane == 17) cb[17] = (uint32_t) slip_ld_i32(&P.row_perm[j]);
             else if (lane == 18) cb[18] = 0u;
             else if (lane == 19) cb[19] = slip_ld_u32(pk + SLIP_PKG_VER);
+            else if (lane == 20) cb[20] = slip_ld_u32(pk + SLIP_PKG_WORKER);
             for (int c = lane; c < 6 * SLIP_PKG_CANDS; c += SLIP_WAVE) cb[32 + c] = slip_ld_u32(pk + SLIP_PKG_CAND + c);
             for (int c = lane; c < SLIP_PKG_NROWMAX; c += SLIP_WAVE) cb[32 + 6 * SLIP_PKG_CANDS + c] = slip_ld_u32(pk + SLIP_PKG_ROWS + c);
         }
@@ -223,7 +225,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             uint32_t *cb = base + i * SLIP_CBW;
             const int nrows = (int) cb[16], ncand = (int) cb[1], stamp = (int) cb[14], stamp0 = (int) cb[15];
             int hit = nrows < 1 || nrows > SLIP_PKG_NROWMAX || ncand < 1 || ncand > SLIP_PKG_CANDS || stamp < stamp0 || stamp > j
-                      || stamp0 < sv[C_RING0] || j - stamp0 > SLIP_CB_RING - SLIP_CB || cb[12] != 0 || cb[19] != hver[i];
+                      || stamp0 < sv[C_RING0] || j - stamp0 > SLIP_CB_RING - SLIP_CB || cb[12] != 0 || cb[19] != hver[i] || cb[20] >= (uint32_t) P.nworkers;
             /* (a package being rewritten: its parts carry different versions -- it will be offered again) */
             if (!hit && lane < ncand && cb[32 + 6 * lane + 5] != hver[i]) hit = 1;
             if (!hit) {
@@ -249,7 +251,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             const int j = kc + i, col = P.q[j];
             uint32_t *cb = base + i * SLIP_CBW;
             const uint32_t *cands = cb + 32, *rows = cb + 32 + 6 * SLIP_PKG_CANDS;
-            uint32_t *pk = P.pkg + (int64_t)(j % P.nworkers) * SLIP_PKG_WORDS;
+            uint32_t *pk = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t)(cb[20] < (uint32_t) P.nworkers ? cb[20] : 0u) * SLIP_MBOX_WORDS;     /* the worker's mailbox */
             const int nrows = (int) cb[16], ncand = (int) cb[1], stamp0 = (int) cb[15];
             const SlipPiv M = *Mrec;
             const int lm = slip_abs(M.len), brho = M.bits, slot = (lm + 3) >> 1;
@@ -476,14 +478,15 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         /* (d) everything issued above has left; then the verdicts and the frontier */
         if (wave == 0) {
             slip_vm_drain();
-            if (lane < nbc) slip_st_u32(P.pkg + (int64_t)((kc + lane) % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_OUT, (hver[lane] << 24) | (uint32_t)(kc + lane + 1));
+            if (lane < nbc) slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t)(base + lane * SLIP_CBW)[20] * SLIP_MBOX_WORDS + SLIP_PKG_OUT, (hver[lane] << 24) | (uint32_t)(kc + lane + 1));
 #ifdef SLIP_PROFILE_PHASES
             if (lane < nbc) P.dbg[18 * (int64_t) P.n + 6 * (int64_t)(kc + lane) + 2] = (int32_t) slip_realtime();  /* time line 2: committed by the committer */
 #endif
             if (lane == 0) {
                 if (rej >= 0) {
                     const uint32_t rv = hver[rej - kc];
-                    slip_st_u32(P.pkg + (int64_t)(rej % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_OUT, (uint32_t)(-(int32_t)((rv << 24) | (uint32_t)(rej + 1))));
+                    const uint32_t rw = (base + (rej - kc) * SLIP_CBW)[20];
+                    if (rw < (uint32_t) P.nworkers) slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) rw * SLIP_MBOX_WORDS + SLIP_PKG_OUT, (uint32_t)(-(int32_t)((rv << 24) | (uint32_t)(rej + 1))));
                     sv[C_REJ] = rej; sv[C_REJV] = (int32_t) rv;
                 }
                 if (nbc > 0) {

@@ -520,7 +520,7 @@ static int alloc_x(slip_hip_factor *f, int32_t xcap, int keep_rows)
         if (P->pkg) hipFree(P->pkg);
         if (P->jobs) hipFree(P->jobs);
         P->pkg = NULL; P->jobs = NULL;
-        if (dev_alloc(&P->pkg, W * (int64_t) SLIP_PKG_WORDS) || dev_alloc(&P->jobs, W * (int64_t) SLIP_JOB_WORDS)) return SLIP_HIP_OUT_OF_MEMORY;
+        if (dev_alloc(&P->pkg, W * (int64_t)(SLIP_PKG_WORDS + SLIP_MBOX_WORDS)) || dev_alloc(&P->jobs, W * (int64_t) SLIP_JOB_WORDS)) return SLIP_HIP_OUT_OF_MEMORY;
         if (hipMemset(P->jobs, 0, (size_t) W * SLIP_JOB_WORDS * 4) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
     }
     return 0;
@@ -749,7 +749,7 @@ extern "C" void slip_emu_set_seed(unsigned long long s) { slip_emu_seed = s; }
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
     f->P.k0 = f->hs.F; f->P.t0 = f->hs.ticket;
-    f->hs.stop = INT64_MAX; f->hs.exited = 0; f->hs.farm_hint = 0;
+    f->hs.stop = INT64_MAX; f->hs.exited = 0; f->hs.farm_hint = 0; f->hs.dbg_who = 0;
     f->P.st = f->ds;
     { const int e = upload_state(f, stream); if (e) return e; }
     /* no more workers than columns left */
@@ -760,7 +760,7 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
     if (W < 1) W = 1;
     if (W < 2) f->P.committer = 0;
     f->P.nworkers = W;
-    if (f->P.committer) CK(hipMemsetAsync(f->P.pkg, 0, (size_t) W * SLIP_PKG_WORDS * 4, stream));
+    if (f->P.committer) CK(hipMemsetAsync(f->P.pkg, 0, (size_t) W * (SLIP_PKG_WORDS + SLIP_MBOX_WORDS) * 4, stream));
     f->P.farm = W >= 2 && !f->no_farm && f->P.jobs != NULL;
     if (f->P.farm) CK(hipMemsetAsync(f->P.jobs, 0, (size_t) W * SLIP_JOB_WORDS * 4, stream));
     CK(hipEventRecord(f->ev0, stream));
@@ -842,8 +842,8 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
             e = grow_x_keep(f, (int64_t) P->xcap * 2, h->F);
             if (e) { rc = e; break; }
         } else {
-            fprintf(stderr, "slip_hip: kernel stopped with internal status %d at column %d (frontier %d, ready %d, stop %lld)\n",
-                    h->status, h->status_k, h->F, h->F2, (long long) h->stop);
+            fprintf(stderr, "slip_hip: kernel stopped with internal status %d at column %d (frontier %d, ready %d, stop %lld; wait %d of column %d: %d %d)\n",
+                    h->status, h->status_k, h->F, h->F2, (long long) h->stop, h->dbg_who, h->dbg_k, h->dbg_a, h->dbg_b);
             rc = SLIP_HIP_DEVICE_ERROR; break;
         }
     }
@@ -1344,6 +1344,8 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
                                         int32_t *pinv)
 {
     if (!f) return SLIP_HIP_INCORRECT_INPUT;
+    /* after a device error the columns between the ready frontier and the commit frontier may be half written: nothing is handed out */
+    if (f->last_status == SLIP_HIP_DEVICE_ERROR) return SLIP_HIP_DEVICE_ERROR;
     const SlipParams *P = &f->P;
     const SlipState *h = &f->hs;
     const int32_t K = h->F;

@@ -282,3 +282,26 @@ def test_gpu_triplet_file_to_factors():
     n, Ap, Ai, Alen, Al = sl.read_triplet(os.path.join(GOLDEN, "test_mat_triplet.txt"))
     res = sl.factorize(n, Ap, Ai, Alen, Al, fix["q"], pivot=entry["pivot"], tol=entry["tol"], kmax=entry["kmax"], limb_cap=entry["cap"])
     check_against_golden(entry, fix, res)
+
+
+@pytest.mark.gpu
+def test_gpu_verdicts_survive_slot_reuse():
+    """two-wave workers are slow to read their verdict: the package slot of column k is reused by column k + workers
+    before that (the verdict lives in the WORKER's mailbox, not in the slot).  Repeated on one handle: every run must
+    end with the reference's factors (a lost verdict used to end in a 20 s spin-limit abort every ~25th run)."""
+    import slip_lu_amd as sl
+    import slabfile
+    entry, fix = load_case("C4_n100k_c64")
+    f = sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], pivot=entry["pivot"], tol=entry["tol"],
+                         limb_cap=entry["cap"], waves=2)
+    try:
+        for rep in range(60):
+            f.reset()
+            rc = f.run(entry["kmax"], check=False)
+            i = f.info()
+            assert rc == 0 and i["K"] == entry["K"], (rep, rc, i["K"])
+            assert i["committer_commits"] > 0
+        d = f.download()
+        assert np.array_equal(d["pinv"], fix["pinv"]) and slabfile.factor_digest(d) == entry["digest"]
+    finally:
+        f.close()
