@@ -1058,6 +1058,9 @@ SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int
 #ifndef SLIP_FARM_MIN_ITEMS
 #define SLIP_FARM_MIN_ITEMS 16          /* ... and shorter queues neither */
 #endif
+#ifndef SLIP_FARM_KIND2
+#define SLIP_FARM_KIND2     0
+#endif
 #ifndef SLIP_FARM_NEAR_DIV
 #define SLIP_FARM_NEAR_DIV  1125        /* ... and only when the column's turn comes before the worker alone would be done */
 #endif
@@ -1078,9 +1081,11 @@ SLIP_DEV int slip_farm_items(const SlipParams &P, uint32_t *jb, int kind, int j,
         if (slip_lane() == 0) t = slip_agent_add_i32((int32_t *)(jb + 16), 1);
         t = (int) slip_bcast0_u32((uint32_t) t);
         if (t >= nq) break;
-        uint32_t it[2];
-        if (wl) { it[0] = wl[2 * t]; it[1] = wl[2 * t + 1]; }
-        else { it[0] = slip_ld_u32(jb + 32 + 2 * t); it[1] = slip_ld_u32(jb + 32 + 2 * t + 1); }
+        uint32_t it[2];                          /* kind 1: (entry, row) pairs; kind 2: rows */
+        if (kind == 1) {
+            if (wl) { it[0] = wl[2 * t]; it[1] = wl[2 * t + 1]; }
+            else { it[0] = slip_ld_u32(jb + 32 + 2 * t); it[1] = slip_ld_u32(jb + 32 + 2 * t + 1); }
+        } else { it[0] = wl ? wl[t] : slip_ld_u32(jb + 32 + t); it[1] = 0u; }
         const int e = slip_run_item_out(&P, kind, j, jn, k, m0, it, 0, b0, b1, b2);
         if (e) err = e;
         cnt++;
@@ -1145,15 +1150,17 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     /* (only a column whose turn is near: further away the worker has the time, and every helper costs its XCD an L2 write-back
      * and invalidate) */
-    if (P.farm && kind == 1 && nq >= SLIP_FARM_MIN_ITEMS && !sv[SV_ERR]) {
-        const int lr = slip_limbs(slip_ld_piv(&P.piv[jn]).len);
+    if (P.farm && (kind == 1 || (kind == 2 && SLIP_FARM_KIND2)) && nq >= SLIP_FARM_MIN_ITEMS && !sv[SV_ERR]) {
+        /* kind 2: the rows of a committed column that still need their division (its readers wait for its stage 2): the
+         * protocol carries them, but helping there measured no gain (C4 6.3 vs 6.1 ms), so it is off */
+        const int lr = slip_limbs(slip_ld_piv(&P.piv[kind == 1 ? jn : k - 1]).len);
         /* the queue alone takes about nq * 8 lr^2 / waves cycles; the frontier moves a column every few microseconds */
         const int64_t cost = (int64_t) nq * lr * lr;
-        if (cost >= SLIP_FARM_MIN_COST && (SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
+        if (cost >= SLIP_FARM_MIN_COST && (kind == 2 || SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
             /* a long queue of long updates: open it to the workers that are waiting */
             const int tid = slip_tid(), T = slip_nthreads();
             uint32_t *jb = P.jobs + (int64_t) P.worker * SLIP_JOB_WORDS;
-            for (int c = tid; c < 2 * nq; c += T) slip_st_u32(jb + 32 + c, wl[c]);
+            for (int c = tid; c < (kind == 1 ? 2 * nq : nq); c += T) slip_st_u32(jb + 32 + c, wl[c]);
             if (tid == 0) {
                 slip_st_u32(jb + 2, (uint32_t) kind); slip_st_u32(jb + 3, (uint32_t) j); slip_st_u32(jb + 4, (uint32_t) jn); slip_st_u32(jb + 5, (uint32_t) k);
                 slip_st_u64((uint64_t *)(jb + 6), (uint64_t) m0); slip_st_u32(jb + 8, (uint32_t) nq); slip_st_u32(jb + 11, 0u); slip_st_u32(jb + 16, 0u);
