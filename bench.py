@@ -332,6 +332,11 @@ def main():
                     bl, bx = np.sign(b).astype(np.int32), np.abs(b[b != 0]).astype(np.uint64)
                     g.solve(bl, bx); g.solve(bl, bx)
                     rec["solve_kernel_ms"] = g.solve_ms()
+                    # right-hand sides run side by side (one worker each): 16 of them, to be read against 16 x the reference's
+                    # one-right-hand-side time below
+                    bl16 = np.tile(bl, 16); bx16 = np.tile(bx, 16)
+                    g.solve(bl16, bx16, nrhs=16)
+                    rec["solve16_kernel_ms"] = g.solve_ms()
                 g.close()
                 if not args.no_cpu_baseline:
                     tf, ts = reference_seconds(name, e, fx)
