@@ -127,9 +127,9 @@ typedef struct SlipSolveArgs {
 } SlipSolveArgs;
 
 #if defined(SLIP_PROFILE_PHASES) && !defined(SLIP_EMULATE)
-#define SLIP_STAMP(slot) do { if (tid == 0) { unsigned long long now_ = clock64(); prof_[slot] += now_ - t_prev_; t_prev_ = now_; } } while (0)
+#define SLIP_STAMP(slot) do { if (tid == 0) { unsigned long long now_ = clock64(); prof_[slot] += now_ - t_prev_; t_prev_ = now_; if (hstamp_) hstamp_[slot] = (int32_t) slip_realtime(); } } while (0)
 #define SLIP_PROFILING 1
-#define SLIP_STAMP_INIT() unsigned long long t_prev_ = clock64(); unsigned long long prof_[24] = {0}
+#define SLIP_STAMP_INIT() unsigned long long t_prev_ = clock64(); unsigned long long prof_[24] = {0}; int32_t *hstamp_ = (int32_t *) 0
 #define SLIP_STAMP_FLUSH(st) do { if (tid == 0) for (int s_ = 0; s_ < 24; s_++) if (prof_[s_]) slip_agent_add_u64(&(st)->prof[s_], prof_[s_]); } while (0)
 #else
 #define SLIP_STAMP(slot) do { } while (0)

@@ -627,6 +627,10 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
 #ifdef SLIP_PROFILING
     if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 5] = (int32_t) slip_realtime();          /* time line 5: the sweep has seen F >= k */
 #endif
+#ifdef SLIP_PROFILING
+    /* a heavy column: the wall-clock time of every phase stamp (tools/phase_probe.py prints them) */
+    if (nrows > 400 && tid == 0) { hstamp_ = P.dbg + 24 * (int64_t) P.n + 32 * (int64_t)(k & 63); for (int q_ = 0; q_ < 32; q_++) hstamp_[q_] = 0; hstamp_[31] = k; hstamp_[30] = nrows; hstamp_[29] = (int32_t) slip_realtime(); }
+#endif
     const int packaged = P.committer && try_early && sv[SV_PKGX];
     slip_block_sync();                                   /* (thread 0 clears the flag below) */
     if (packaged) for (;;) {

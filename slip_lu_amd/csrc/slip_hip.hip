@@ -678,9 +678,9 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     A_(dev_alloc(&f->dAp, (int64_t) n + 1)); A_(dev_alloc(&f->dAi, onz)); A_(dev_alloc(&f->dAlen, onz));
     A_(dev_alloc(&f->dAoff, onz)); A_(dev_alloc(&f->dAlimbs, ol)); A_(dev_alloc(&f->dq, n));
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n)); A_(dev_alloc(&P->sw_row, n)); A_(dev_alloc(&P->sw_pos, n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n + 4096)); A_(dev_alloc(&P->sw_row, n)); A_(dev_alloc(&P->sw_pos, n));
     A_(make_ident(f));
-    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 24 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->dbg, 0, ((size_t) n * 24 + 4096) * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc && hipMemset(P->piv, 0, (size_t) n * sizeof(SlipPiv)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     /* initial sizes: S->lnz/unz only size the first allocation in the reference too */
     P->Lcap_nz = opt.lnz_hint > 0 ? opt.lnz_hint : 4 * onz + n;
@@ -926,11 +926,11 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     int rc = 0;
 #define A_(call) do { if (!rc) rc = (call); } while (0)
     A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n)); A_(dev_alloc(&P->sw_row, n)); A_(dev_alloc(&P->sw_pos, n));
+    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n + 4096)); A_(dev_alloc(&P->sw_row, n)); A_(dev_alloc(&P->sw_pos, n));
     A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Lo, (int64_t) n + 1)); A_(dev_alloc(&P->Li, lnz)); A_(dev_alloc(&P->Le, lnz)); A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
     A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Uo, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, unz)); A_(dev_alloc(&P->Ue, unz)); A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
     A_(dev_alloc(&f->ds, 1));
-    if (!rc && hipMemset(P->dbg, 0, (size_t) n * 24 * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->dbg, 0, ((size_t) n * 24 + 4096) * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     if (!rc) rc = alloc_x(f, 2 * maxdig + 8, 0);
 #undef A_
 #define UP_(dst, src, bytes) do { if (!rc && (bytes) > 0 && hipMemcpy((void *)(dst), (src), (size_t)(bytes), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR; } while (0)
@@ -1236,6 +1236,15 @@ extern "C" int slip_hip_factor_phase_cycles(const slip_hip_factor *f, unsigned l
     return SLIP_HIP_OK;
 }
 
+/* diagnostic builds: wall-clock phase stamps of the heavy columns (more than 400 rows), 64 records of 32 words
+ * (slot s = time of SLIP_STAMP(s); 29 = chain start, 30 = rows, 31 = column) */
+extern "C" int slip_hip_factor_heavy_trace(const slip_hip_factor *f, int32_t *out2048)
+{
+    if (!f || !out2048) return SLIP_HIP_INCORRECT_INPUT;
+    CK(hipMemcpy(out2048, f->P.dbg + 24 * (int64_t) f->n, 2048 * 4, hipMemcpyDeviceToHost));
+    return SLIP_HIP_OK;
+}
+
 /* diagnostic builds: the per-column trace (8 words per column: commit-chain cycles, early flag, candidates computed, rows,
  * cycles of the sweep after the last frontier wait, of the early pass, of the publish, worker) */
 extern "C" int slip_hip_factor_column_trace(const slip_hip_factor *f, int32_t *out, int32_t ncols)
@@ -1248,6 +1257,7 @@ extern "C" int slip_hip_factor_column_trace(const slip_hip_factor *f, int32_t *o
     CK(hipMemcpy(out + 9 * (int64_t) ncols, f->P.dbg + 9 * (int64_t) f->n, (size_t) ncols * 8 * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(out + 17 * (int64_t) ncols, f->P.dbg + 17 * (int64_t) f->n, (size_t) ncols * 4, hipMemcpyDeviceToHost));      /* path flags */
     CK(hipMemcpy(out + 18 * (int64_t) ncols, f->P.dbg + 18 * (int64_t) f->n, (size_t) ncols * 6 * 4, hipMemcpyDeviceToHost));  /* wall-clock time line, 6 words per column */
+
     return SLIP_HIP_OK;
 }
 

@@ -60,4 +60,16 @@ for name in sys.argv[1].split(","):
             if e.any():
                 print(f"    early columns: sweep-tail+snapshot mean {tr[e, 4].mean():.0f}, pass+publish mean {tr[e, 5].mean():.0f} "
                       f"median {np.median(tr[e, 5]):.0f}")
+    if hasattr(f.lib, "slip_hip_factor_heavy_trace") and os.environ.get("SLIP_HEAVY"):
+        import numpy as np
+        hv = np.zeros(2048, np.int32)
+        f.lib.slip_hip_factor_heavy_trace.argtypes = [C.c_void_p, C.c_void_p]
+        f.lib.slip_hip_factor_heavy_trace(f.h, hv.ctypes.data)
+        hv = hv.reshape(64, 32)
+        for rec in hv:
+            if rec[30] <= 0:
+                continue
+            t0 = int(rec[29]) & 0xFFFFFFFF
+            stamps = sorted(((int(rec[s_]) - t0) & 0xFFFFFFFF, s_) for s_ in range(24) if rec[s_] != 0)
+            print(f"    heavy col {rec[31]} rows {rec[30]}: " + ", ".join(f"{SLOTS.get(s_, s_)}@{t / 100.0:.0f}us" for t, s_ in stamps))
     f.close()
