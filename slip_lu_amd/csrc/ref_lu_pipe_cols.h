@@ -1374,6 +1374,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 if (e && lane == 0) sv[SV_ERR] = 1;
             }
             slip_block_sync();
+            SLIP_STAMP(11);                                   /* the products of the class-A rows */
             slip_drain(P, lds, 2, 0, 0, k, 0, nq, wl, b0, b1, b2);
             SLIP_STAMP(10);
             if (tid == 0) { *wcnt = 0; *wcnt2 = 0; sv64[SV_LALLOC / 2] = (int64_t) lalloc_now; }

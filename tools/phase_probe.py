@@ -10,7 +10,7 @@ import slip_lu_amd as sl
 path = os.environ.get("SLIP_PROF_LIB") or os.path.join(ROOT, "slip_lu_amd", "csrc", "libslip_hip_prof.so")
 SLOTS = {0: "scatter", 1: "sweep(work)", 16: "wait F", 17: "wait F2", 20: "  sweep after last F wait", 2: "position snapshot",
          21: "early: classify", 22: "early: reduce+candidates", 13: "early: search+diag (or full search)", 6: "stage1 publish",
-         14: "pattern+rank", 8: "hist:stage rho", 9: "hist:classify", 10: "hist:mul+drain",
+         14: "pattern+rank", 8: "hist:stage rho", 9: "hist:classify", 11: "hist:mul (class A)", 10: "hist:drain (divisions)",
          3: "hist:rest", 12: "table+cap", 4: "diag rule", 5: "offsets", 7: "stage2 copy",
          18: "CRITICAL: F seen -> F stored", 23: "(early commits per column)", 15: "(early candidates computed per column)"}
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 0
