@@ -1061,6 +1061,9 @@ SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int
 #ifndef SLIP_FARM_KIND2
 #define SLIP_FARM_KIND2     0
 #endif
+#ifndef SLIP_FARM_KIND2_COST
+#define SLIP_FARM_KIND2_COST 262144     /* items * limbs^2: only the heavy columns */
+#endif
 #ifndef SLIP_FARM_NEAR_DIV
 #define SLIP_FARM_NEAR_DIV  1125        /* ... and only when the column's turn comes before the worker alone would be done */
 #endif
@@ -1151,12 +1154,13 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
     /* (only a column whose turn is near: further away the worker has the time, and every helper costs its XCD an L2 write-back
      * and invalidate) */
     if (P.farm && (kind == 1 || (kind == 2 && SLIP_FARM_KIND2)) && nq >= SLIP_FARM_MIN_ITEMS && !sv[SV_ERR]) {
-        /* kind 2: the rows of a committed column that still need their division (its readers wait for its stage 2): the
-         * protocol carries them, but helping there measured no gain (C4 6.3 vs 6.1 ms), so it is off */
+        /* kind 2: the rows of a committed column that still need their division (its readers wait for its stage 2).  The
+         * protocol carries them and a 700-row column of the C4 window then takes 0.35 ms instead of 1.5 -- but the window as a
+         * whole got slower (median 6.37 against 6.06 ms over 30 runs: every helper costs its XCD an L2 invalidate), so: off */
         const int lr = slip_limbs(slip_ld_piv(&P.piv[kind == 1 ? jn : k - 1]).len);
         /* the queue alone takes about nq * 8 lr^2 / waves cycles; the frontier moves a column every few microseconds */
         const int64_t cost = (int64_t) nq * lr * lr;
-        if (cost >= SLIP_FARM_MIN_COST && (kind == 2 || SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
+        if (cost >= (kind == 2 ? (int64_t) SLIP_FARM_KIND2_COST : (int64_t) SLIP_FARM_MIN_COST) && (kind == 2 || SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
             /* a long queue of long updates: open it to the workers that are waiting */
             const int tid = slip_tid(), T = slip_nthreads();
             uint32_t *jb = P.jobs + (int64_t) P.worker * SLIP_JOB_WORDS;

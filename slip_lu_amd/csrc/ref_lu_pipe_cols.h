@@ -1026,7 +1026,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     if (ec < 0) {
     /* class of a row for the early commit: 0 not a candidate (pivotal or zero), 1 exact (value at level k-1 in its x
      * row), 2 pending A (one limb times the long pivot -> straight into the L slab), 3 pending B (wave item) */
-    uint64_t ulimbs = 0, lbound = 0; int nUc = 0, bad = 0, maxub = 0; uint32_t best_b = kind == 1 ? 0u : 0xFFFFFFFFu;
+    uint64_t ulimbs = 0, lbound = 0; int nUc = 0, bad = 0, maxub = 0, maxlb = 0; uint32_t best_b = kind == 1 ? 0u : 0xFFFFFFFFu;
     volatile int32_t *acnt = &sv[SV_ACNT];               /* zero since the column started: no barrier needed before the first slot is drawn */
     for (int t0 = 0; t0 < nrows; t0 += T) {
         const int t = t0 + tid;
@@ -1042,7 +1042,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         }
         if (try_early && t < nrows) {
             const SlipRow xr = (t0 == 0 && !fastc) ? xr0_ : P.xrow[r];
-            if (pos < k) { ulimbs += (uint64_t) slip_limbs(xr.len); nUc++; if (xr.bits > maxub) maxub = xr.bits; }
+            if (pos < k) { ulimbs += (uint64_t) slip_limbs(xr.len); nUc++; if (xr.bits > maxub) maxub = xr.bits; if (xr.bits > maxlb) maxlb = xr.bits; }
             else if (xr.len == 0) cls = 0;
             else if (xr.h >= k - 1) {
                 cls = 1; ub = xr.bits; lbound += (uint64_t) slip_limbs(xr.len);
@@ -1076,6 +1076,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 }
             }
             if (ub > maxub) maxub = ub;
+            /* what the value certainly reaches (the window cap is decided on it when it is already beyond the cap) */
+            { const int lb_ = cls == 1 ? ub : (cls == 2 ? ub - 1 : (cls == 3 ? (ub > 2 ? ub - 2 : 1) : 0)); if (lb_ > maxlb) maxlb = lb_; }
         }
         if (try_early) {
             /* class A rows get their slots in the L slab now (slot index kept in the row's own x area, behind the value) */
@@ -1125,25 +1127,29 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         {
             const uint32_t w_u = slip_wave_sum_u32((uint32_t) ulimbs), w_l = slip_wave_sum_u32((uint32_t) lbound);
             const uint32_t w_n = slip_wave_sum_u32((uint32_t) nUc), w_bad = slip_wave_max_u32((uint32_t) bad);
-            const uint32_t w_mx = slip_wave_max_u32((uint32_t) maxub);
+            const uint32_t w_mx = slip_wave_max_u32((uint32_t) maxub), w_lb = slip_wave_max_u32((uint32_t) maxlb);
             const uint32_t w_b = slip_wave_min_u32(kind == 1 ? 0xFFFFFFFFu - best_b : best_b);     /* smaller is better in every kind */
             if (lane == 0) {
                 uint32_t *rp = (uint32_t *) scan_tmp + 8 * wave;
-                rp[0] = w_u; rp[1] = w_l; rp[2] = w_n; rp[3] = w_bad; rp[4] = w_mx; rp[5] = w_b;
+                rp[0] = w_u; rp[1] = w_l; rp[2] = w_n; rp[3] = w_bad; rp[4] = w_mx; rp[5] = w_b; rp[6] = w_lb;
             }
         }
         slip_block_sync();
-        uint64_t U_l = 0, L_b = 0; uint32_t nUc_all = 0, bad_all = 0, maxub_all = 0, bb = 0xFFFFFFFFu;
+        uint64_t U_l = 0, L_b = 0; uint32_t nUc_all = 0, bad_all = 0, maxub_all = 0, maxlb_all = 0, bb = 0xFFFFFFFFu;
         for (int w = 0; w < nw; w++) {
             const uint32_t *rp = (const uint32_t *) scan_tmp + 8 * w;
             U_l += rp[0]; L_b += rp[1]; nUc_all += rp[2];
             if (rp[3] > bad_all) bad_all = rp[3];
             if (rp[4] > maxub_all) maxub_all = rp[4];
             if (rp[5] < bb) bb = rp[5];
+            if (rp[6] > maxlb_all) maxlb_all = rp[6];
         }
         SLIP_STAMP(21);                                     /* early: classification + reduction */
         SLIP_TR(3);                                         /* 3: wave reduce + barrier + combine */
         if (bb == 0xFFFFFFFFu) return SLIPDEV_SINGULAR;      /* no nonzero non-pivotal row at all (slip_get_smallest_pivot.c:93-96) */
+        /* column-window mode: a value whose LOWER bound is beyond the cap ends the window here, without the arithmetic of
+         * the complete path (the last column of a window used to cost a millisecond to say so) */
+        if (P.limb_cap > 0 && (int)((maxlb_all + 63) >> 6) > P.limb_cap) return SLIPDEV_WINDOW_END;
         const int nA = *acnt;
         const uint32_t bestb = kind == 1 ? 0xFFFFFFFFu - bb : bb;
         const int nLc = nrows - (int) nUc_all;

@@ -17,7 +17,7 @@ for rep in range(reps):
         print(rep, "rc", rc, "K", i["K"], "launches", i["launches"], "short", i["short_commits"], "committer", i["committer_commits"], "farm", i["farm_jobs"], i["farm_items"], "ms", round(i["kernel_ms"], 2), flush=True)
         continue
     f = sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], pivot=entry["pivot"], tol=entry["tol"],
-                         limb_cap=entry["cap"], waves=waves, workers=workers, debug_flags=flags)
+                         limb_cap=entry["cap"], waves=waves, workers=workers, debug_flags=flags, **({"lib_path": os.environ["SLIP_PROBE_LIB"]} if os.environ.get("SLIP_PROBE_LIB") else {}))
     rc = f.run(entry["kmax"], check=False)
     i = f.info()
     print(rep, "rc", rc, "K", i["K"], "launches", i["launches"], "short", i["short_commits"], "committer", i["committer_commits"], "farm", i["farm_jobs"], i["farm_items"], "ms", round(i["kernel_ms"], 2), flush=True)
