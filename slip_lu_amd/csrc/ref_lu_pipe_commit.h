@@ -101,7 +101,9 @@ template <int D> SLIP_DEV void slip_commit_mul(const WR<D> &Mr, uint32_t a0, uin
 }
 
 /* LDS of the committer, words from lds + SLIP_LDS_WORK (the lists, tables and keys of a column worker: 12288 words) */
+#ifndef SLIP_CB
 #define SLIP_CB          8                  /* columns per batch */
+#endif
 #define SLIP_CB_RING     512                /* swaps the committer remembers (more than the columns in flight) */
 #define SLIP_CBW         (32 + 6 * SLIP_PKG_CANDS + SLIP_PKG_NROWMAX)      /* one batch column: sums, candidates, rows */
 #define SLIP_CB_SLOTW    262                /* a product of a one-limb value and a pivot of at most 256 digits, whole limbs */
