@@ -78,7 +78,7 @@ typedef struct SlipState {
     int32_t F2; int32_t padF2[31];                  /* ready frontier: columns < F2 have published their L entries (stage 2) */
     int32_t ticket; int32_t padT[31];               /* next column ticket (monotonic across launches)                    */
     int32_t exited, padE[31];                       /* workers that have left the launch (the last one writes the summary) */
-    int32_t farm_hint, padH[31];
+    int32_t farm_hint[8], padH[24];                 /* +-(worker + 1) of workers whose update queue is open to helpers (slot worker % 8, last writer wins; hints; negative: the bulk of a committed column) */
     int32_t dbg_who, dbg_k, dbg_a, dbg_b;           /* which wait ran into the spin limit (diagnostic) */                    /* worker + 1 of a worker whose update queue is open to helpers (last writer wins; a hint) */
     int32_t k_next, status, status_k, solve_next;
     int64_t Lnz, Lnl, Unz, Unl;                     /* mirrors of Lp/Lo/Up/Uo at the frontier (written at kernel end)     */
@@ -1059,7 +1059,7 @@ SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int
 #define SLIP_FARM_MIN_ITEMS 16          /* ... and shorter queues neither */
 #endif
 #ifndef SLIP_FARM_KIND2
-#define SLIP_FARM_KIND2     0
+#define SLIP_FARM_KIND2     1
 #endif
 #ifndef SLIP_FARM_KIND2_COST
 #define SLIP_FARM_KIND2_COST 262144     /* items * limbs^2: only the heavy columns */
@@ -1098,12 +1098,18 @@ SLIP_DEV int slip_farm_items(const SlipParams &P, uint32_t *jb, int kind, int j,
 }
 
 /* thread 0 of a waiting worker: is there a job to help with?  returns slot + 1, or 0 */
-SLIP_DEV int slip_farm_peek(const SlipParams &P, SlipState *st)
+/* urgent_only: the caller's own turn is near -- it only helps with queues the frontier waits for (kind 1: the hint is
+ * positive), not with the bulk of committed columns (kind 2: negative) */
+SLIP_DEV int slip_farm_peek(const SlipParams &P, SlipState *st, int urgent_only = 0)
 {
     if (!P.farm) return 0;
-    const int h = slip_ld_i32(&st->farm_hint);
-    if (h <= 0 || h - 1 == P.worker || h > P.nworkers) return 0;
-    return (slip_ld_u32(P.jobs + (int64_t)(h - 1) * SLIP_JOB_WORDS) & 1u) ? h : 0;
+    for (int q = 0; q < 8; q++) {
+        int h = slip_ld_i32(&st->farm_hint[(P.worker + q) & 7]);
+        if (h < 0) { if (urgent_only) continue; h = -h; }
+        if (h <= 0 || h - 1 == P.worker || h > P.nworkers) continue;
+        if (slip_ld_u32(P.jobs + (int64_t)(h - 1) * SLIP_JOB_WORDS) & 1u) return h;
+    }
+    return 0;
 }
 
 /* all threads of a waiting worker: help with the job in `slot` */
@@ -1171,14 +1177,14 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
             }
             slip_vm_drain();
             slip_block_sync();
-            if (tid == 0) { slip_agent_release(); slip_agent_add_i32((int32_t *) jb, 1); slip_st_i32(&P.st->farm_hint, P.worker + 1); slip_agent_add_u64(&P.st->c_farm, 1ull); }
+            if (tid == 0) { slip_agent_release(); slip_agent_add_i32((int32_t *) jb, 1); slip_st_i32(&P.st->farm_hint[P.worker & 7], kind == 1 ? P.worker + 1 : -(P.worker + 1)); slip_agent_add_u64(&P.st->c_farm, 1ull); }
             const int e = slip_farm_items(P, jb, kind, j, jn, k, m0, nq, wl, b0, b1, b2);
             if (e && lane == 0) sv[SV_ERR] = e;
             slip_vm_drain();
             slip_block_sync();
             if (tid == 0) {
                 slip_agent_add_i32((int32_t *) jb, -1);                          /* closed: nobody new gets in */
-                if (slip_ld_i32(&P.st->farm_hint) == P.worker + 1) slip_st_i32(&P.st->farm_hint, 0);
+                { const int hh = slip_ld_i32(&P.st->farm_hint[P.worker & 7]); if (hh == P.worker + 1 || hh == -(P.worker + 1)) slip_st_i32(&P.st->farm_hint[P.worker & 7], 0); }
                 unsigned long long spins = 0;
                 while ((slip_agent_add_i32((int32_t *) jb, 0) >> 8) != 0) { slip_sleep_short(); if (++spins > SLIP_SPIN_LIMIT) { sv[SV_ERR] = SLIPDEV_INTERNAL; P.st->dbg_who = 5; P.st->dbg_k = sv[SV_K]; P.st->dbg_a = slip_agent_add_i32((int32_t *) jb, 0); break; } }
                 const int he = (int) slip_ld_u32(jb + 11);

@@ -32,7 +32,7 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, i
             if (F >= need) { res = F; sv[SV_TMP3] = pr; break; }       /* pr = row_perm[F-1], for free */
             if (once) { res = F; break; }                               /* a look, not a wait: the caller has something to do meanwhile */
             /* nothing to do but wait: is another worker's update queue open to helpers?  (-2 - slot: the caller helps, then waits again) */
-            if (Pf) { const int h = slip_farm_peek(*Pf, st); if (h) { res = -1 - h; break; } }
+            if (Pf) { const int h = slip_farm_peek(*Pf, st, k - F <= 48); if (h) { res = -1 - h; break; } }
             const int64_t stop = slip_ld_i64(&st->stop);
             if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             /* the further from its turn, the longer between polls: the frontier word is one line for the whole chip */
@@ -643,7 +643,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 if (v == -mine_) { res = 0; break; }
                 const int64_t stop = slip_ld_i64(&st->stop);
                 if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
-                { const int h = slip_farm_peek(P, st); if (h) { res = -1 - h; break; } }
+                { const int h = slip_farm_peek(P, st, 1); if (h) { res = -1 - h; break; } }
                 slip_sleep_short();
                 if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 3; st->dbg_k = k; st->dbg_a = v; st->dbg_b = mine_; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
             }

@@ -749,7 +749,7 @@ extern "C" void slip_emu_set_seed(unsigned long long s) { slip_emu_seed = s; }
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
     f->P.k0 = f->hs.F; f->P.t0 = f->hs.ticket;
-    f->hs.stop = INT64_MAX; f->hs.exited = 0; f->hs.farm_hint = 0; f->hs.dbg_who = 0;
+    f->hs.stop = INT64_MAX; f->hs.exited = 0; for (int q_ = 0; q_ < 8; q_++) f->hs.farm_hint[q_] = 0; f->hs.dbg_who = 0;
     f->P.st = f->ds;
     { const int e = upload_state(f, stream); if (e) return e; }
     /* no more workers than columns left */
