@@ -112,7 +112,7 @@ typedef struct SlipParams {
     int32_t no_early;                               /* diagnostics: 1 = every column takes the complete path (no early commit) */
     int32_t committer;                              /* 1: block 0 of the launch is the committer (ref_lu_pipe_commit.h), the others are column workers */
     uint32_t *pkg;                                  /* shared: one package slot per worker (SLIP_PKG_WORDS words each)      */
-    uint32_t *jobs; int32_t farm, pad_f; SlipState *st;            /* shared: one job slot per worker (SLIP_JOB_WORDS words): a long update queue other workers help with */
+    uint32_t *jobs; int32_t farm, in_factor; SlipState *st;     /* in_factor: a factorisation launch (the stop word names columns) */            /* shared: one job slot per worker (SLIP_JOB_WORDS words): a long update queue other workers help with */
     int32_t *sw_row, *sw_pos;                       /* shared: the swap log -- column c's pivot changed places with row sw_row[c] (= row_perm[c] before), which moved to position sw_pos[c] (= the pivot row's position before) */
     int64_t priv_rows;                              /* rows per worker of the private arrays (= n)                      */
     int32_t *dbg;
@@ -1197,10 +1197,17 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
     }
     if (!sv[SV_ERR])
         for (int t = wave; t < nq; t += nw) {
+            /* a column beyond the one that stopped the factorisation can never commit: its long queues are not worth finishing
+             * (the launch ends when the last workgroup leaves).  One wave looks at the stop word between its items. */
+            if (P.in_factor && kind == 1) {
+                if (wave == nw - 1 && lane == 0 && (slip_ld_i64(&P.st->stop) >> 8) < (int64_t) sv[SV_K]) sv[SV_ABORT] = 1;
+                if (sv[SV_ABORT]) break;
+            }
             const int e = slip_run_item_out(&P, kind, j, jn, k, m0, wl, t, b0, b1, b2);
             if (e && lane == 0) sv[SV_ERR] = e;
         }
     slip_block_sync();
+    if (P.in_factor && kind == 1 && sv[SV_ABORT] && !sv[SV_ERR]) { slip_block_sync(); if (slip_tid() == 0) sv[SV_ERR] = 100; slip_block_sync(); }    /* = SLIPDEV_ABORTED: the column is given up */
 }
 
 #include "ref_lu_pipe_cols.h"

@@ -550,7 +550,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     /* ---- phase 0: clear the pattern bitmap, take a snapshot of the commit frontier ---- */
     for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
     if (tid == 0) {
-        sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv[SV_NROWS] = 0; sv[SV_ACNT] = 0; sv[SV_EST] = -1; sv[SV_PP] = 0; sv[SV_PKGX] = 0; sv[SV_PKGVER] = 0;
+        sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv[SV_NROWS] = 0; sv[SV_ACNT] = 0; sv[SV_EST] = -1; sv[SV_PP] = 0; sv[SV_PKGX] = 0; sv[SV_PKGVER] = 0; sv[SV_ABORT] = 0;
         sv64[SV_LALLOC / 2] = 0; sv64[SV_LEXACT / 2] = 0;
         /* the ready frontier first: it never passes the commit frontier, also not between the two loads */
         sv[SV_F2] = slip_ld_i32(&st->F2);

@@ -750,7 +750,7 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
     f->P.k0 = f->hs.F; f->P.t0 = f->hs.ticket;
     f->hs.stop = INT64_MAX; f->hs.exited = 0; for (int q_ = 0; q_ < 8; q_++) f->hs.farm_hint[q_] = 0; f->hs.dbg_who = 0;
-    f->P.st = f->ds;
+    f->P.st = f->ds; f->P.in_factor = 1;
     { const int e = upload_state(f, stream); if (e) return e; }
     /* no more workers than columns left */
     int32_t W = f->nworkers;
@@ -957,7 +957,7 @@ static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, int32_t *rhs
 {
     f->P.t0 = f->hs.ticket;
     f->hs.stop = INT64_MAX; f->hs.exited = 0;
-    f->P.farm = 0; f->P.committer = 0; f->P.st = f->ds;
+    f->P.farm = 0; f->P.committer = 0; f->P.st = f->ds; f->P.in_factor = 0;
     { const int e = upload_state(f, stream); if (e) return e; }
     int32_t W = f->nworkers;
     if (W > A.nrhs) W = A.nrhs;
