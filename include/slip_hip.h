@@ -104,11 +104,15 @@ int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *info);
  *   rholen[K], rholimbs[sum |rholen|], pinv[n]
  * Row indices are ORIGINAL row ids in the reference's entry order
  * (SLIP_LU_factorize.c:226-263); apply pinv for the final relabel (:293-301).
- * Any pointer may be NULL to skip that array.  rho_limbs_out: in = capacity in
- * limbs, out = limbs written. */
+ * Any pointer may be NULL to skip that array.  Every limb array travels with its
+ * capacity: *_limbs_inout: in = capacity of the array in limbs, out = limbs written
+ * (required whenever the array is given).  The entry records on the device are checked
+ * against the device's own limb counters and against the slab before anything is
+ * copied: an inconsistency is SLIP_HIP_DEVICE_ERROR, a short array SLIP_HIP_INCORRECT_INPUT;
+ * in neither case is a limb array written. */
 int slip_hip_factor_download(const slip_hip_factor *f,
-                             int64_t *Lp, int32_t *Li, int32_t *Llen, uint64_t *Llimbs,
-                             int64_t *Up, int32_t *Ui, int32_t *Ulen, uint64_t *Ulimbs,
+                             int64_t *Lp, int32_t *Li, int32_t *Llen, uint64_t *Llimbs, int64_t *L_limbs_inout,
+                             int64_t *Up, int32_t *Ui, int32_t *Ulen, uint64_t *Ulimbs, int64_t *U_limbs_inout,
                              int32_t *rholen, uint64_t *rholimbs, int64_t *rho_limbs_inout,
                              int32_t *pinv);
 
@@ -138,10 +142,10 @@ double slip_hip_factor_solve_ms(const slip_hip_factor *f);
 /* Subtree farm (no counterpart in the reference, which has no parallelism): multiply the K committed
  * columns by per-column scales on the device -- L(:,k) and rho[k] by scale[k], an entry of U in the row whose pivot sits
  * at position p by scale[p] -- where scale[k] is the product of the pivots the OTHER independent blocks had produced when
- * global column k was eliminated (slip_lu_amd/parallel.py: subtree_scales).  scale[k]: signed limb counts slen[K], limbs back
- * to back.  The rescaled copy is what slip_hip_factor_download / _info then serve, until the next reset (or rescale);
+ * global column k was eliminated (slip_lu_amd/parallel.py: subtree_scales).  scale[k]: signed limb counts slen[nscales], limbs back
+ * to back; nscales must equal the K committed columns (SLIP_HIP_INCORRECT_INPUT otherwise).  The rescaled copy is what slip_hip_factor_download / _info then serve, until the next reset (or rescale);
  * the handle's own factors are untouched, so run / solve keep working on the local values. */
-int slip_hip_factor_rescale(slip_hip_factor *f, const int32_t *slen, const uint64_t *slimbs, void *stream);
+int slip_hip_factor_rescale(slip_hip_factor *f, int32_t nscales, const int32_t *slen, const uint64_t *slimbs, void *stream);
 
 void slip_hip_factor_destroy(slip_hip_factor *f);
 

@@ -60,7 +60,8 @@ def load(path=None):
     lib.slip_hip_factor_reset.argtypes = [vp]
     lib.slip_hip_factor_run.argtypes = [vp, C.c_int32, vp]
     lib.slip_hip_factor_info.argtypes = [vp, C.POINTER(Info)]
-    lib.slip_hip_factor_download.argtypes = [vp] + [vp] * 10 + [C.POINTER(C.c_int64), vp]
+    lib.slip_hip_factor_download.argtypes = ([vp] + [vp] * 4 + [C.POINTER(C.c_int64)] + [vp] * 4 + [C.POINTER(C.c_int64)]
+                                             + [vp] * 2 + [C.POINTER(C.c_int64), vp])
     lib.slip_hip_factor_destroy.argtypes = [vp]
     lib.slip_hip_factor_destroy.restype = None
     lib.slip_hip_matgen.argtypes = [C.c_int32, C.c_double, C.c_int32, C.c_uint64,
@@ -75,7 +76,7 @@ def load(path=None):
     lib.slip_hip_factor_solve.restype = C.c_int
     lib.slip_hip_factor_from_factors.argtypes = [C.POINTER(vp), C.c_int32] + [vp] * 9 + [C.POINTER(Options)]
     lib.slip_hip_factor_from_factors.restype = C.c_int
-    lib.slip_hip_factor_rescale.argtypes = [vp, vp, vp, vp]
+    lib.slip_hip_factor_rescale.argtypes = [vp, C.c_int32, vp, vp, vp]
     lib.slip_hip_factor_rescale.restype = C.c_int
     lib.slip_hip_factor_solve_ms.argtypes = [vp]
     lib.slip_hip_factor_solve_ms.restype = C.c_double

@@ -135,8 +135,9 @@ class Factorization:
         self.lib.slip_hip_factor_info(self.h, C.byref(i))
         return {k: getattr(i, k) for k, _ in _lib.Info._fields_}
 
-    def download(self):
-        """Factor arrays in the canonical form the tests compare (original row ids)."""
+    def download(self, limb_capacity=None):
+        """Factor arrays in the canonical form the tests compare (original row ids).  limb_capacity: the capacity to CLAIM for
+        the L limb array (tests of the capacity check; the array itself is always sized from info())."""
         i = self.info()
         K = i["K"]
         out = dict(n=self.n, K=K, status=i["status"],
@@ -148,14 +149,15 @@ class Factorization:
         # pivots are entries of L: an upper bound of their limbs is l_limbs
         rho = np.zeros(max(i["l_limbs"], 1), np.uint64)
         cap = C.c_int64(rho.size)
+        lcap, ucap = C.c_int64(limb_capacity if limb_capacity is not None else out["Llimbs"].size), C.c_int64(out["Ulimbs"].size)
         rc = self.lib.slip_hip_factor_download(
-            self.h, out["Lp"].ctypes.data, out["Li"].ctypes.data, out["Llen"].ctypes.data, out["Llimbs"].ctypes.data,
-            out["Up"].ctypes.data, out["Ui"].ctypes.data, out["Ulen"].ctypes.data, out["Ulimbs"].ctypes.data,
+            self.h, out["Lp"].ctypes.data, out["Li"].ctypes.data, out["Llen"].ctypes.data, out["Llimbs"].ctypes.data, C.byref(lcap),
+            out["Up"].ctypes.data, out["Ui"].ctypes.data, out["Ulen"].ctypes.data, out["Ulimbs"].ctypes.data, C.byref(ucap),
             out["rholen"].ctypes.data, rho.ctypes.data, C.byref(cap), out["pinv"].ctypes.data)
         if rc:
             raise SlipError(rc, "slip_hip_factor_download")
-        out["Llimbs"] = out["Llimbs"][:i["l_limbs"]]
-        out["Ulimbs"] = out["Ulimbs"][:i["u_limbs"]]
+        out["Llimbs"] = out["Llimbs"][:lcap.value]
+        out["Ulimbs"] = out["Ulimbs"][:ucap.value]
         out["rholimbs"] = rho[:cap.value].copy()
         out["counters"] = np.array([i["n_upd"], i["b_read"], i["b_write"], i["n_src"], i["l_streamed"],
                                     i["max_limbs"], K, i["limb_macs"]], dtype=np.int64)
@@ -190,7 +192,7 @@ class Factorization:
         rholen = np.zeros(max(K, 1), np.int32)
         rho = np.zeros(max(i["l_limbs"], 1), np.uint64)
         cap = C.c_int64(rho.size)
-        rc = self.lib.slip_hip_factor_download(self.h, None, None, None, None, None, None, None, None,
+        rc = self.lib.slip_hip_factor_download(self.h, None, None, None, None, None, None, None, None, None, None,
                                                rholen.ctypes.data, rho.ctypes.data, C.byref(cap), None)
         if rc:
             raise SlipError(rc, "slip_hip_factor_download")
@@ -206,7 +208,10 @@ class Factorization:
                 limbs.append(a & (2 ** 64 - 1)); a >>= 64; l += 1
             lens.append(-l if v < 0 else l)
         lens = np.array(lens, np.int32); limbs = np.array(limbs if limbs else [0], np.uint64)
-        rc = self.lib.slip_hip_factor_rescale(self.h, lens.ctypes.data, limbs.ctypes.data, C.c_void_p(stream or 0))
+        K = self.info()["K"]
+        if len(lens) != K:
+            raise ValueError(f"rescale needs one scale per committed column: {len(lens)} given, K = {K}")
+        rc = self.lib.slip_hip_factor_rescale(self.h, int(len(lens)), lens.ctypes.data, limbs.ctypes.data, C.c_void_p(stream or 0))
         if rc:
             raise SlipError(rc, "slip_hip_factor_rescale")
 

@@ -257,6 +257,7 @@ struct slip_hip_factor {
     int32_t n; int64_t annz, alimbs;
     int32_t waves, lds_words, bitmap_in_lds, scratch_in_lds;
     int32_t nworkers;      /* column workers = workgroups of a launch; private arrays are sized for this many */
+    int32_t workers_asked; /* slip_hip_options.workers (0: as many as can be resident) */
     int32_t no_committer;  /* diagnostics: every column is committed by its own worker */
     int32_t no_farm;       /* diagnostics: long update queues are not opened to other workers */
     int32_t last_status, window_end, launches;
@@ -457,9 +458,14 @@ static void plan_launch(slip_hip_factor *f)
     P->bitmap_in_lds = f->bitmap_in_lds; P->scratch_in_lds = f->scratch_in_lds;
 }
 
+#ifdef SLIP_EMULATE
+/* test hooks of the CPU emulation build (never in the product library) */
+static int64_t slip_emu_budget = 96ll << 30;
+extern "C" void slip_emu_set_budget(long long bytes) { slip_emu_budget = bytes > 0 ? bytes : (96ll << 30); }
+#endif
 /* how many column workers: as many as can be resident (LDS-limited workgroups per CU times the CUs), capped by the
  * columns there are and by what their private vectors may take of the HBM */
-static int32_t default_workers(const slip_hip_factor *f, int32_t xcap)
+static int32_t default_workers(const slip_hip_factor *f, int32_t xcap, int32_t asked)
 {
     int cus = 256;
 #ifndef SLIP_EMULATE
@@ -475,9 +481,13 @@ static int32_t default_workers(const slip_hip_factor *f, int32_t xcap)
     const int by_waves = 8 / (f->waves > 0 ? f->waves : 1);           /* 232 VGPRs: two waves per SIMD, eight per CU */
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
-    int64_t w = (int64_t) cus * per_cu;
+    int64_t w = asked > 0 ? asked : (int64_t) cus * per_cu;
     const int64_t per_worker = (int64_t) f->n * (16 + 4 * (int64_t) xcap + 16) + 4096;
+#ifdef SLIP_EMULATE
+    const int64_t budget = slip_emu_budget;                             /* tests shrink it to force the re-application at a wider stride */
+#else
     const int64_t budget = 96ll << 30;                                  /* of the 288 GB */
+#endif
     if (w * per_worker > budget) w = budget / per_worker;
     if (w > f->n) w = f->n;
     if (w < 1) w = 1;
@@ -489,40 +499,46 @@ static int32_t default_workers(const slip_hip_factor *f, int32_t xcap)
 static int alloc_x(slip_hip_factor *f, int32_t xcap, int keep_rows)
 {
     SlipParams *P = &f->P;
-    if (P->xd) hipFree(P->xd);
-    if (P->invd) hipFree(P->invd);
-    if (P->gscratch) hipFree(P->gscratch);
-    if (P->gbitmap) hipFree(P->gbitmap);
-    P->xd = NULL; P->invd = NULL; P->gscratch = NULL; P->gbitmap = NULL;
     xcap = (xcap + 3) & ~3;
+    /* plan for the new stride on a copy: the handle keeps its working buffers until every new one exists */
+    const int32_t old_xcap = P->xcap, old_invcap = P->invcap, old_waves = f->waves;
     P->xcap = xcap; P->invcap = xcap + 8;
     plan_launch(f);
-    if (f->nworkers <= 0) f->nworkers = default_workers(f, xcap);
-    const int64_t W = f->nworkers, n = P->n;
-    P->nworkers = f->nworkers; P->priv_rows = n;
-    if (!keep_rows) {
-        if (P->xrow) hipFree(P->xrow);
-        if (P->pat) hipFree(P->pat);
-        if (P->rlist) hipFree(P->rlist);
-        if (P->rpos) hipFree(P->rpos);
-        if (P->srow) hipFree(P->srow);
-        P->xrow = NULL; P->pat = NULL; P->rlist = NULL; P->rpos = NULL; P->srow = NULL;
-        if (dev_alloc(&P->xrow, W * n) || dev_alloc(&P->pat, W * n) || dev_alloc(&P->rlist, W * n) ||
-            dev_alloc(&P->rpos, W * n) || dev_alloc(&P->srow, W * n)) return SLIP_HIP_OUT_OF_MEMORY;
+    /* how many workers: what was asked for (or what can be resident), never more than the HBM budget allows at THIS stride,
+     * and never more than the private row arrays were sized for */
+    int32_t W32 = default_workers(f, xcap, f->workers_asked);
+    if (keep_rows && f->nworkers > 0 && W32 > f->nworkers) W32 = f->nworkers;
+    const int64_t W = W32, n = P->n;
+    uint32_t *nxd = NULL, *ninvd = NULL, *ngs = NULL, *ngb = NULL;
+    int rc = 0;
+    if (dev_alloc(&nxd, W * n * xcap) || dev_alloc(&ninvd, n * (int64_t) P->invcap) ||
+        dev_alloc(&ngs, f->scratch_in_lds ? 1 : W * SLIP_SCRATCH_WAVES * 3 * (int64_t) P->wcap) ||
+        dev_alloc(&ngb, f->bitmap_in_lds ? 1 : W * ((int64_t) P->bm_words + 64))) rc = SLIP_HIP_OUT_OF_MEMORY;
+    SlipRow *nxrow = NULL; int32_t *npat = NULL, *nrlist = NULL, *nrpos = NULL, *nsrow = NULL; uint32_t *npkg = NULL, *njobs = NULL;
+    if (!rc && !keep_rows) {
+        if (dev_alloc(&nxrow, W * n) || dev_alloc(&npat, W * n) || dev_alloc(&nrlist, W * n) ||
+            dev_alloc(&nrpos, W * n) || dev_alloc(&nsrow, W * n)) rc = SLIP_HIP_OUT_OF_MEMORY;
         /* tags start at 0 = "belongs to no column"; tickets count from 1 */
-        if (hipMemset(P->xrow, 0, (size_t)(W * n) * sizeof(SlipRow)) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
+        else if (hipMemset(nxrow, 0, (size_t)(W * n) * sizeof(SlipRow)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     }
-    if (dev_alloc(&P->xd, W * n * xcap)) return SLIP_HIP_OUT_OF_MEMORY;
-    if (dev_alloc(&P->invd, n * (int64_t) P->invcap)) return SLIP_HIP_OUT_OF_MEMORY;
-    if (dev_alloc(&P->gscratch, f->scratch_in_lds ? 1 : W * SLIP_SCRATCH_WAVES * 3 * (int64_t) P->wcap)) return SLIP_HIP_OUT_OF_MEMORY;
-    if (dev_alloc(&P->gbitmap, f->bitmap_in_lds ? 1 : W * ((int64_t) P->bm_words + 64))) return SLIP_HIP_OUT_OF_MEMORY;
-    if (!keep_rows || !P->pkg) {
-        if (P->pkg) hipFree(P->pkg);
-        if (P->jobs) hipFree(P->jobs);
-        P->pkg = NULL; P->jobs = NULL;
-        if (dev_alloc(&P->pkg, W * (int64_t)(SLIP_PKG_WORDS + SLIP_MBOX_WORDS)) || dev_alloc(&P->jobs, W * (int64_t) SLIP_JOB_WORDS)) return SLIP_HIP_OUT_OF_MEMORY;
-        if (hipMemset(P->jobs, 0, (size_t) W * SLIP_JOB_WORDS * 4) != hipSuccess) return SLIP_HIP_DEVICE_ERROR;
+    if (!rc && (!keep_rows || !P->pkg)) {
+        if (dev_alloc(&npkg, W * (int64_t)(SLIP_PKG_WORDS + SLIP_MBOX_WORDS)) || dev_alloc(&njobs, W * (int64_t) SLIP_JOB_WORDS)) rc = SLIP_HIP_OUT_OF_MEMORY;
+        else if (hipMemset(njobs, 0, (size_t) W * SLIP_JOB_WORDS * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     }
+    if (rc) {
+        /* nothing of the handle has been touched: it stays usable at the old stride */
+        hipFree(nxd); hipFree(ninvd); hipFree(ngs); hipFree(ngb); hipFree(nxrow); hipFree(npat); hipFree(nrlist); hipFree(nrpos); hipFree(nsrow); hipFree(npkg); hipFree(njobs);
+        if (old_xcap > 0) { P->xcap = old_xcap; P->invcap = old_invcap; f->waves = old_waves; plan_launch(f); }
+        return rc;
+    }
+    hipFree(P->xd); hipFree(P->invd); hipFree(P->gscratch); hipFree(P->gbitmap);
+    P->xd = nxd; P->invd = ninvd; P->gscratch = ngs; P->gbitmap = ngb;
+    if (!keep_rows) {
+        hipFree(P->xrow); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow);
+        P->xrow = nxrow; P->pat = npat; P->rlist = nrlist; P->rpos = nrpos; P->srow = nsrow;
+    }
+    if (npkg) { hipFree(P->pkg); hipFree(P->jobs); P->pkg = npkg; P->jobs = njobs; }
+    f->nworkers = W32; P->nworkers = W32; P->priv_rows = n;
     return 0;
 }
 
@@ -537,7 +553,14 @@ extern "C" int slip_hip_factor_reset(slip_hip_factor *f)
     if (!f || f->factors_only) return SLIP_HIP_INCORRECT_INPUT;
     SlipParams *P = &f->P;
     const int32_t n = f->n;
+    if (!P->xd || !P->xrow) return SLIP_HIP_OUT_OF_MEMORY;
     if (f->rescaled) rescale_drop(f);
+    /* tickets double as row tags and are never reused -- until they would wrap: then every private row is untagged and
+     * the count starts over (a launch draws at most one ticket per column plus one per worker) */
+    if (f->hs.ticket > (1 << 30)) {
+        CK(hipMemsetAsync(P->xrow, 0, (size_t)((int64_t) f->nworkers * n) * sizeof(SlipRow), 0));
+        f->hs.ticket = 0;
+    }
     CK(hipMemcpyAsync(P->pinv, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
     CK(hipMemcpyAsync(P->row_perm, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
     CK(hipMemsetAsync(P->Lready, 0, (size_t) n * 4, 0));
@@ -577,11 +600,11 @@ static void apply_options(slip_hip_factor *f, const slip_hip_options &opt)
 {
     f->waves = opt.waves > 0 ? opt.waves : 8;
     if (f->waves > SLIP_MAX_WAVES) f->waves = SLIP_MAX_WAVES;
-    f->nworkers = opt.workers > 0 ? opt.workers : 0;      /* 0: chosen in alloc_x once the LDS need is known */
+    f->workers_asked = opt.workers > 0 ? (opt.workers > 4096 ? 4096 : opt.workers) : 0;
+    f->nworkers = 0;       /* chosen in alloc_x once the LDS need is known */
     f->P.no_early = opt.reserved & 1;
     f->no_committer = (opt.reserved >> 1) & 1;
     f->no_farm = (opt.reserved >> 2) & 1;
-    if (f->nworkers > 4096) f->nworkers = 4096;
 }
 
 static int make_ident(slip_hip_factor *f)
@@ -611,6 +634,8 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
     slip_hip_options opt;
     if (opt_in) opt = *opt_in; else slip_hip_default_options(&opt);
     if (opt.pivot < 0 || opt.pivot > 5) return SLIP_HIP_INCORRECT_INPUT;
+    /* column and row numbers travel in 24-bit fields of the commit protocol (verdict words, package records) */
+    if (n >= (1 << 24) - 1) return SLIP_HIP_INCORRECT_INPUT;
     const int64_t annz = Ap[n];
     if (Ap[0] != 0 || annz < 1) return SLIP_HIP_INCORRECT_INPUT;
 
@@ -729,10 +754,9 @@ static int grow_x_keep(slip_hip_factor *f, int64_t xcap, int32_t K)
         if (!keep) return SLIP_HIP_OUT_OF_MEMORY;
         if (hipMemcpy(keep, P->piv, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(keep); return SLIP_HIP_DEVICE_ERROR; }
     }
-    /* a wider stride may change how many workers fit; fewer never hurts, so the count only shrinks */
-    const int32_t old_workers = f->nworkers;
+    /* a wider stride may change how many workers fit: alloc_x re-applies the HBM budget at the new stride and never goes
+     * beyond the count the private row arrays were sized for; on failure the handle keeps its old buffers */
     int e = alloc_x(f, (int32_t) xcap, 1);
-    if (!e && f->nworkers > old_workers) f->nworkers = f->P.nworkers = old_workers;
     if (!e && K > 0) {
         for (int32_t k = 0; k < K; k++) keep[k].invlen = 0;
         if (hipMemcpy(P->piv, keep, (size_t) K * sizeof(SlipPiv), hipMemcpyHostToDevice) != hipSuccess) e = SLIP_HIP_DEVICE_ERROR;
@@ -744,6 +768,14 @@ static int grow_x_keep(slip_hip_factor *f, int64_t xcap, int32_t K)
 #ifdef SLIP_EMULATE
 static unsigned long long slip_emu_seed = 1;
 extern "C" void slip_emu_set_seed(unsigned long long s) { slip_emu_seed = s; }
+/* overwrite the length of entry t of L (isU 0) or U (isU 1): what a protocol error on the device would leave behind */
+extern "C" int slip_emu_corrupt_entry(slip_hip_factor *f, int isU, long long t, int newlen)
+{
+    if (!f || t < 0 || t >= (isU ? f->hs.Unz : f->hs.Lnz)) return -1;
+    SlipEnt *e = (isU ? f->P.Ue : f->P.Le) + t;
+    e->len = newlen;
+    return 0;
+}
 #endif
 
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
@@ -817,6 +849,7 @@ extern "C" int slip_hip_factor_run(slip_hip_factor *f, int32_t kmax, void *strea
     hipStream_t stream = (hipStream_t) stream_v;
     SlipParams *P = &f->P;
     SlipState *h = &f->hs;
+    if (!P->xd || !P->xrow) return SLIP_HIP_OUT_OF_MEMORY;
     if (kmax <= 0 || kmax > f->n) kmax = f->n;
     f->kernel_ms = 0; f->launches = 0; f->window_end = 0;
     P->k_stop = kmax;
@@ -920,7 +953,7 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     SlipParams *P = &f->P;
     f->n = n; f->factors_only = 1;
     apply_options(f, opt);
-    if (f->nworkers <= 0) f->nworkers = 64;            /* right-hand sides in flight; more are taken in turn */
+    if (f->workers_asked <= 0) f->workers_asked = 64;  /* right-hand sides in flight; more are taken in turn */
     P->n = n; P->pivot_scheme = opt.pivot; P->limb_cap = 0; P->k_stop = n;
     P->Lcap_nz = lnz; P->Ucap_nz = unz; P->Lcap_nl = lnl > 0 ? lnl : 1; P->Ucap_nl = unl > 0 ? unl : 1;
     int rc = 0;
@@ -1008,6 +1041,7 @@ extern "C" int slip_hip_factor_solve(slip_hip_factor *f, int32_t nrhs, const int
     *xlen_out = NULL; *xlimbs_out = NULL; *xnl_out = 0;
     const int32_t n = f->n;
     if (f->hs.F != n) return SLIP_HIP_INCORRECT_INPUT;          /* needs the complete factorisation */
+    if (!f->P.xd || !f->P.xrow) return SLIP_HIP_OUT_OF_MEMORY;
     hipStream_t stream = (hipStream_t) stream_v;
     SlipParams *P = &f->P;
     const int64_t ne = (int64_t) n * nrhs;
@@ -1176,12 +1210,12 @@ static int rescale_one(slip_hip_factor *f, int isL, int64_t nz, int64_t nl_alloc
     return rc;
 }
 
-extern "C" int slip_hip_factor_rescale(slip_hip_factor *f, const int32_t *slen, const uint64_t *slimbs, void *stream_v)
+extern "C" int slip_hip_factor_rescale(slip_hip_factor *f, int32_t nscales, const int32_t *slen, const uint64_t *slimbs, void *stream_v)
 {
     if (!f || !slen || !slimbs) return SLIP_HIP_INCORRECT_INPUT;
     hipStream_t stream = (hipStream_t) stream_v;
     const int32_t K = f->hs.F;
-    if (K <= 0) return SLIP_HIP_INCORRECT_INPUT;
+    if (K <= 0 || nscales != K) return SLIP_HIP_INCORRECT_INPUT;      /* one scale per committed column, no more, no fewer */
     /* scales: signed limb counts -> signed digit counts + limb offsets */
     int32_t *hd = (int32_t *) malloc((size_t) K * 4), *habs = (int32_t *) malloc((size_t) K * 4);
     int64_t *ho = (int64_t *) malloc((size_t) K * 8);
@@ -1294,12 +1328,32 @@ __global__ void __launch_bounds__(256) slip_gather_kernel(const SlipEnt *ent, co
 }
 #endif
 
-static int fetch_factor(int32_t *len_out, uint64_t *limbs_out, const SlipEnt *dev_ent, const uint64_t *dev_limbs, int64_t nz, int64_t nl_alloc)
+/* `expect`: the limbs the device counted for these entries (SlipState.Lnl_exact / Unl_exact, or the rescaled totals);
+ * `cap`: what the caller's limbs_out can hold.  Nothing is written to limbs_out unless the entry records are consistent
+ * with both and every entry lies inside the slab (nl_alloc limbs): device state never sizes a write into host memory. */
+static int fetch_factor(int32_t *len_out, uint64_t *limbs_out, const SlipEnt *dev_ent, const uint64_t *dev_limbs, int64_t nz, int64_t nl_alloc,
+                        int64_t expect, int64_t cap, int64_t *written)
 {
+    if (written) *written = 0;
     if (nz <= 0) return 0;
     SlipEnt *ent = (SlipEnt *) malloc((size_t) nz * sizeof(SlipEnt));
     if (!ent) return SLIP_HIP_OUT_OF_MEMORY;
     if (hipMemcpy(ent, dev_ent, (size_t) nz * sizeof(SlipEnt), hipMemcpyDeviceToHost) != hipSuccess) { free(ent); return SLIP_HIP_DEVICE_ERROR; }
+    /* the records first: lengths, offsets and the total against what the device counted */
+    int64_t total = 0;
+    for (int64_t t = 0; t < nz; t++) {
+        const int64_t d = ent[t].len < 0 ? -(int64_t) ent[t].len : ent[t].len, l = (d + 1) >> 1;
+        if (d > (int64_t) 1 << 30 || ent[t].off < 0 || (l > 0 && ent[t].off + l > nl_alloc)) {
+            fprintf(stderr, "slip_hip: entry record %lld is inconsistent (off %lld, %lld digits, slab %lld limbs)\n", (long long) t, (long long) ent[t].off, (long long) d, (long long) nl_alloc);
+            free(ent); return SLIP_HIP_DEVICE_ERROR;
+        }
+        total += l;
+    }
+    if (total != expect) {
+        fprintf(stderr, "slip_hip: the entry records hold %lld limbs, the device counted %lld\n", (long long) total, (long long) expect);
+        free(ent); return SLIP_HIP_DEVICE_ERROR;
+    }
+    if (limbs_out && total > cap) { free(ent); return SLIP_HIP_INCORRECT_INPUT; }
     if (len_out)
         for (int64_t t = 0; t < nz; t++) {
             int32_t d = ent[t].len, a = d < 0 ? -d : d;
@@ -1307,28 +1361,25 @@ static int fetch_factor(int32_t *len_out, uint64_t *limbs_out, const SlipEnt *de
             len_out[t] = d < 0 ? -a : a;
         }
     int rc = 0;
-    if (limbs_out && nl_alloc > 0) {
+    if (limbs_out && total > 0) {
 #ifndef SLIP_EMULATE
         /* one pass on the device, then one copy of exactly the packed limbs */
         int64_t *ooff = (int64_t *) malloc(((size_t) nz + 1) * 8), *d_ooff = NULL; uint64_t *d_out = NULL;
         if (!ooff) { free(ent); return SLIP_HIP_OUT_OF_MEMORY; }
         ooff[0] = 0;
         for (int64_t t = 0; t < nz; t++) { const int32_t d = ent[t].len; ooff[t + 1] = ooff[t] + (((d < 0 ? -d : d) + 1) >> 1); }
-        const int64_t total = ooff[nz];
-        if (total > 0) {
-            if (dev_alloc(&d_ooff, nz + 1) || dev_alloc(&d_out, total)) rc = SLIP_HIP_OUT_OF_MEMORY;
-            else if (hipMemcpy(d_ooff, ooff, ((size_t) nz + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
-            else {
-                int64_t blocks = (nz + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-                hipLaunchKernelGGL(slip_gather_kernel, dim3((unsigned) blocks), dim3(256), 0, 0, dev_ent, dev_limbs, d_ooff, d_out, nz);
-                if (hipGetLastError() != hipSuccess || hipMemcpy(limbs_out, d_out, (size_t) total * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
-            }
-            if (d_ooff) hipFree(d_ooff);
-            if (d_out) hipFree(d_out);
+        if (dev_alloc(&d_ooff, nz + 1) || dev_alloc(&d_out, total)) rc = SLIP_HIP_OUT_OF_MEMORY;
+        else if (hipMemcpy(d_ooff, ooff, ((size_t) nz + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+        else {
+            int64_t blocks = (nz + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+            hipLaunchKernelGGL(slip_gather_kernel, dim3((unsigned) blocks), dim3(256), 0, 0, dev_ent, dev_limbs, d_ooff, d_out, nz);
+            if (hipGetLastError() != hipSuccess || hipMemcpy(limbs_out, d_out, (size_t) total * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
         }
+        if (d_ooff) hipFree(d_ooff);
+        if (d_out) hipFree(d_out);
         free(ooff);
 #else
-        uint64_t *raw = (uint64_t *) malloc((size_t) nl_alloc * 8);
+        uint64_t *raw = (uint64_t *) malloc((size_t)(nl_alloc > 0 ? nl_alloc : 1) * 8);
         if (!raw) rc = SLIP_HIP_OUT_OF_MEMORY;
         else if (hipMemcpy(raw, dev_limbs, (size_t) nl_alloc * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
         else {
@@ -1343,17 +1394,20 @@ static int fetch_factor(int32_t *len_out, uint64_t *limbs_out, const SlipEnt *de
         free(raw);
 #endif
     }
+    if (!rc && written) *written = total;
     free(ent);
     return rc;
 }
 
 extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
-                                        int64_t *Lp, int32_t *Li, int32_t *Llen, uint64_t *Llimbs,
-                                        int64_t *Up, int32_t *Ui, int32_t *Ulen, uint64_t *Ulimbs,
+                                        int64_t *Lp, int32_t *Li, int32_t *Llen, uint64_t *Llimbs, int64_t *L_limbs_inout,
+                                        int64_t *Up, int32_t *Ui, int32_t *Ulen, uint64_t *Ulimbs, int64_t *U_limbs_inout,
                                         int32_t *rholen, uint64_t *rholimbs, int64_t *rho_limbs_inout,
                                         int32_t *pinv)
 {
     if (!f) return SLIP_HIP_INCORRECT_INPUT;
+    /* a limb array without its capacity cannot be written safely */
+    if ((Llimbs && !L_limbs_inout) || (Ulimbs && !U_limbs_inout) || (rholimbs && !rho_limbs_inout)) return SLIP_HIP_INCORRECT_INPUT;
     /* after a device error the columns between the ready frontier and the commit frontier may be half written: nothing is handed out */
     if (f->last_status == SLIP_HIP_DEVICE_ERROR) return SLIP_HIP_DEVICE_ERROR;
     const SlipParams *P = &f->P;
@@ -1364,8 +1418,15 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
     if (Up) CK(hipMemcpy(Up, P->Up, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost));
     if (Li && h->Lnz) CK(hipMemcpy(Li, P->Li, (size_t) h->Lnz * 4, hipMemcpyDeviceToHost));
     if (Ui && h->Unz) CK(hipMemcpy(Ui, P->Ui, (size_t) h->Unz * 4, hipMemcpyDeviceToHost));
-    if ((Llen || Llimbs) && (e = fetch_factor(Llen, Llimbs, f->rescaled ? f->rsLe : P->Le, f->rescaled ? f->rsLl : P->Llimbs, h->Lnz, f->rescaled ? f->rsLnl : h->Lnl))) return e;
-    if ((Ulen || Ulimbs) && (e = fetch_factor(Ulen, Ulimbs, f->rescaled ? f->rsUe : P->Ue, f->rescaled ? f->rsUl : P->Ulimbs, h->Unz, f->rescaled ? f->rsUnl : h->Unl))) return e;
+    {
+        int64_t wl = 0, wu = 0;
+        if ((Llen || Llimbs) && (e = fetch_factor(Llen, Llimbs, f->rescaled ? f->rsLe : P->Le, f->rescaled ? f->rsLl : P->Llimbs, h->Lnz, f->rescaled ? f->rsLnl : P->Lcap_nl,
+                                                  f->rescaled ? f->rsLexact : h->Lnl_exact, L_limbs_inout ? *L_limbs_inout : 0, &wl))) return e;
+        if ((Ulen || Ulimbs) && (e = fetch_factor(Ulen, Ulimbs, f->rescaled ? f->rsUe : P->Ue, f->rescaled ? f->rsUl : P->Ulimbs, h->Unz, f->rescaled ? f->rsUnl : P->Ucap_nl,
+                                                  f->rescaled ? f->rsUexact : h->Unl_exact, U_limbs_inout ? *U_limbs_inout : 0, &wu))) return e;
+        if (L_limbs_inout) *L_limbs_inout = wl;
+        if (U_limbs_inout) *U_limbs_inout = wu;
+    }
     if (pinv) CK(hipMemcpy(pinv, P->pinv, (size_t) f->n * 4, hipMemcpyDeviceToHost));
     if ((rholen || rholimbs) && K > 0) {
         /* the pivots live in the L slab: gather them through the pivot records (a rescaled copy: through the pivot entries) */
@@ -1391,6 +1452,7 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
         for (int32_t k = 0; k < K && !rc; k++) {
             int32_t d = pr[k].len, l = ((d < 0 ? -d : d) + 1) >> 1;
             if (rholen) rholen[k] = d < 0 ? -l : l;
+            if (pr[k].off < 0 || pr[k].off + l > (f->rescaled ? f->rsLnl : P->Lcap_nl)) { rc = SLIP_HIP_DEVICE_ERROR; break; }
             if (rholimbs) {
                 if (o + l > capl) { rc = SLIP_HIP_INCORRECT_INPUT; break; }
                 if (hipMemcpy(rholimbs + o, Lsrc + pr[k].off, (size_t) l * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;

@@ -127,9 +127,11 @@ SLIP_info SLIP_hip_LU_factorize(SLIP_sparse *L, SLIP_sparse *U, SLIP_sparse *A, 
     rholimbs = (uint64_t *) malloc((size_t)(info.l_limbs ? info.l_limbs : 1) * 8);
     if (!Lp || !Up || !Li || !Ui || !Llen || !Ulen || !Llimbs || !Ulimbs || !rholen || !rholimbs) goto done;
     {
-        int64_t rcap = info.l_limbs;
-        if (slip_hip_factor_download(f, Lp, Li, Llen, Llimbs, Up, Ui, Ulen, Ulimbs, rholen, rholimbs, &rcap, pinv) != SLIP_HIP_OK)
+        /* every limb array goes with its capacity: the library checks the device's records against them before it writes */
+        int64_t rcap = info.l_limbs ? info.l_limbs : 1, lcap = info.l_limbs ? info.l_limbs : 1, ucap = info.u_limbs ? info.u_limbs : 1;
+        if (slip_hip_factor_download(f, Lp, Li, Llen, Llimbs, &lcap, Up, Ui, Ulen, Ulimbs, &ucap, rholen, rholimbs, &rcap, pinv) != SLIP_HIP_OK)
             goto done;
+        if (lcap != info.l_limbs || ucap != info.u_limbs) goto done;
     }
 
     clock_gettime(CLOCK_MONOTONIC, &t3_);
