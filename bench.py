@@ -170,6 +170,44 @@ def profile_traffic(kernel_ms):
         return None, None
 
 
+def chain_report(fac, K, kernel_ms, info):
+    """The bound that actually holds on this workload: the columns commit in order (K hops), and a column
+    whose pattern holds an earlier pivot row depends on that column's L (the source DAG).  From the factors just
+    downloaded: sources per column = rows of U(:,k) above the pivot with a nonzero value; depth = longest chain of such
+    dependencies.  hop_us_measured = kernel time / K; lower_bound_ms = K x the committer's measured serial time per column
+    (profiles/r*/..._commit.json of the newest profile, if one is committed) + depth x one cross-chip hand-off (1 us,
+    MI355X_MICROARCH.md handoff-1to1)."""
+    import numpy as np
+    Up, Ui, Ulen, pinv = fac["Up"], fac["Ui"], fac["Ulen"], fac["pinv"]
+    depth = np.zeros(K, np.int64); nsrc = 0; ncols_src = 0
+    for k in range(K):
+        rows = Ui[Up[k]:Up[k + 1] - 1]; lens = Ulen[Up[k]:Up[k + 1] - 1]
+        src = pinv[rows][lens != 0]
+        if len(src):
+            depth[k] = depth[src].max() + 1; nsrc += len(src); ncols_src += 1
+    serial_us = None; src_file = None
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*", "*_commit.json")):
+        try:
+            key = (int(os.path.basename(os.path.dirname(path))[1:]), int(os.path.basename(path).split("_")[0][1:]))
+        except ValueError:
+            continue
+        if best is None or key > best[0]:
+            best = (key, path)
+    if best:
+        try:
+            serial_us = json.load(open(best[1])).get("serial_us_per_column"); src_file = os.path.relpath(best[1], ROOT)
+        except Exception:
+            pass
+    out = {"columns_on_chain": int(K), "hop_us_measured": 1e3 * kernel_ms / max(K, 1),
+           "source_applications": int(nsrc), "columns_with_sources": int(ncols_src), "source_dag_depth": int(depth.max()) if K else 0,
+           "committer_commits": info["committer_commits"], "engine_commits": info["engine_commits"],
+           "committer_serial_us_per_column": serial_us, "committer_profile": src_file}
+    if serial_us is not None:
+        out["lower_bound_ms"] = (K * serial_us + int(depth.max()) * 1.0) * 1e-3
+    return out
+
+
 def farm_mode(args, sl, parallel, torch, dist, rank, world, stream):
     """--farm: the subtree farm of SURVEY 8(e) on a C5-shaped BLOCK matrix (n = 200k, 100 nonzeros per column, made of
     independent diagonal blocks whose columns interleave in the elimination order): every rank factorises its blocks'
@@ -304,6 +342,12 @@ def main():
     idx = {e["name"]: e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "index.json")))}[w["golden"]]
     assert K == idx["K"] and nnz == idx["lnz"] + idx["unz"] - idx["K"], "benchmark run differs from the reference window"
     assert info["b_read"] == idx["counters"]["B_read"] and info["b_write"] == idx["counters"]["B_write"]
+    # ... and bit for bit: the factors of the LAST timed step against the reference's digest (a wrong pivot with equal counts
+    # would otherwise be timed as a pass)
+    import slabfile
+    fac = f.download()
+    assert slabfile.factor_digest(fac) == idx["digest"], "benchmark run: factor digest differs from the reference's"
+    chain = chain_report(fac, K, kernel_ms / args.steps, info)
 
     ms_per_step = 1e3 * elapsed / args.steps
     kms = kernel_ms / args.steps                       # HIP-event time of the column-loop kernel per launch
@@ -370,7 +414,8 @@ def main():
                      "alu": {"limb_macs": info["limb_macs"], "digit_macs_per_s": digit_macs, "peak": DIGIT_MAC_PEAK,
                              "frac": digit_macs / DIGIT_MAC_PEAK,
                              "note": "algorithmic: 4 x (l(L_m) l(x_j) + l(x_i) l(rho_jn)) 32-bit multiply-adds per IPGE update "
-                                     "(SURVEY 8(d)); peak = v_mad_u64_u32 at a quarter of the VALU lane rate"}},
+                                     "(SURVEY 8(d)); peak = v_mad_u64_u32 at a quarter of the VALU lane rate"},
+                     "chain": chain},
     }
     if secondary:
         out["secondary"] = secondary

@@ -49,7 +49,7 @@ typedef struct slip_hip_options {
     int64_t unz_hint;     /*   cf. SLIP_LU_analysis.lnz/.unz; both grow on demand      */
     int32_t workers;      /* column workers (workgroups of a launch; each owns a private */
                           /*   dense vector): 0 = as many as can be resident            */
-    int32_t reserved;     /* diagnostics: bit 0 = no early commit, bit 1 = no committer workgroup, bit 2 = no helping with long update queues */
+    int32_t reserved;     /* diagnostics: bit 0 = no early commit, bit 1 = no committer workgroup, bit 2 = no helping with long update queues, bit 3 = no full packages (chain engine off) */
 } slip_hip_options;
 
 typedef struct slip_hip_info {
@@ -70,6 +70,8 @@ typedef struct slip_hip_info {
     int32_t short_commits;    /* columns whose pivot was published by the short commit chain (diagnostic) */
     int32_t committer_commits;         /* ... of those, by the committer workgroup */
     int32_t farm_jobs, farm_items, pad2;   /* update queues opened to helpers; items helpers ran (diagnostic) */
+    int32_t engine_commits, engine_sources; /* columns committed by the committer's chain engine from FULL packages; late sources it applied */
+    int32_t retractions, reexports;        /* packages a worker took back because a source arrived; packages exported again */
 } slip_hip_info;
 
 typedef struct slip_hip_factor slip_hip_factor;

@@ -25,7 +25,8 @@ class Info(C.Structure):
                 ("l_streamed", C.c_int64), ("max_limbs", C.c_int64),
                 ("kernel_ms", C.c_double), ("launches", C.c_int32), ("xcap_digits", C.c_int32),
                 ("limb_macs", C.c_int64), ("workers", C.c_int32), ("waves", C.c_int32),
-                ("lds_bytes", C.c_int32), ("short_commits", C.c_int32), ("committer_commits", C.c_int32), ("farm_jobs", C.c_int32), ("farm_items", C.c_int32), ("pad2", C.c_int32)]
+                ("lds_bytes", C.c_int32), ("short_commits", C.c_int32), ("committer_commits", C.c_int32), ("farm_jobs", C.c_int32), ("farm_items", C.c_int32), ("pad2", C.c_int32),
+                ("engine_commits", C.c_int32), ("engine_sources", C.c_int32), ("retractions", C.c_int32), ("reexports", C.c_int32)]
 
 
 EXPORTS = ("slip_hip_default_options", "slip_hip_device_count", "slip_hip_factor_create",

@@ -79,12 +79,14 @@ typedef struct SlipState {
     int32_t ticket; int32_t padT[31];               /* next column ticket (monotonic across launches)                    */
     int32_t exited, padE[31];                       /* workers that have left the launch (the last one writes the summary) */
     int32_t farm_hint[8], padH[24];                 /* +-(worker + 1) of workers whose update queue is open to helpers (slot worker % 8, last writer wins; hints; negative: the bulk of a committed column) */
-    int32_t dbg_who, dbg_k, dbg_a, dbg_b;           /* which wait ran into the spin limit (diagnostic) */                    /* worker + 1 of a worker whose update queue is open to helpers (last writer wins; a hint) */
+    int32_t committer_up, committer_where, padC[30];                 /* the committer workgroup of this launch is running (workers export packages only after they have seen it) */
+    int32_t dbg_who, dbg_k, dbg_a, dbg_b;           /* which wait ran into the spin limit (diagnostic) */
     int32_t k_next, status, status_k, solve_next;
     int64_t Lnz, Lnl, Unz, Unl;                     /* mirrors of Lp/Lo/Up/Uo at the frontier (written at kernel end)     */
     int64_t Lnl_exact, Unl_exact;                   /* limbs actually stored                                             */
     int64_t out_used;                               /* solve: limbs of the output slab in use                            */
-    unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig, c_macs, c_short, c_farm;   /* c_farm: queues opened to helpers (low word), items helpers ran (high word) */    /* c_short: columns committed by the short chain */
+    unsigned long long c_upd, c_read, c_write, c_src, c_streamed, c_maxdig, c_macs, c_short, c_farm;   /* c_farm: queues opened to helpers (low word), items helpers ran (high word); c_short: columns committed by the short chain (high word: by the committer) */
+    unsigned long long c_eng, c_retract;            /* c_eng: columns committed by the committer's chain engine (low word), late sources it applied (high word); c_retract: packages retracted (low), exported again (high) */
     unsigned long long prof[24];                    /* -DSLIP_PROFILE_PHASES builds only */
 } SlipState;
 
@@ -111,6 +113,8 @@ typedef struct SlipParams {
     int32_t nworkers, worker;
     int32_t no_early;                               /* diagnostics: 1 = every column takes the complete path (no early commit) */
     int32_t committer;                              /* 1: block 0 of the launch is the committer (ref_lu_pipe_commit.h), the others are column workers */
+    int32_t quiet_neighbours;                       /* workers on CUs within this distance of the committer's stand aside (they share its instruction cache) */
+    int32_t engine;                                 /* 1: the committer keeps a mirror of pinv in LDS and runs the chain engine (full packages of short one-limb columns) */
     uint32_t *pkg;                                  /* shared: one package slot per worker (SLIP_PKG_WORDS words each)      */
     uint32_t *jobs; int32_t farm, in_factor; SlipState *st;     /* in_factor: a factorisation launch (the stop word names columns) */            /* shared: one job slot per worker (SLIP_JOB_WORDS words): a long update queue other workers help with */
     int32_t *sw_row, *sw_pos;                       /* shared: the swap log -- column c's pivot changed places with row sw_row[c] (= row_perm[c] before), which moved to position sw_pos[c] (= the pivot row's position before) */
@@ -163,6 +167,9 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
        SV_TMP2 = 28, SV_F2 = 29 /* ready frontier as this worker knows it */, SV_TMP3 = 30, SV_ACNT = 31 /* class-A rows of the early commit (zeroed at column start) */,
        SV_EPR = 32, SV_EPP = 33, SV_EST = 34 /* early commit: pivot row, its position, status (written by wave 0) */,
        SV_PP = 36 /* SLIP_PP_WORDS words: what the pre-pass of the commit chain found (slip_prepass) */,
+       SV_PPF = 50 /* pre-pass: non-pivotal rows of a column that can travel as a FULL package (every value one limb), or -1 */,
+       SV_PKGK = 51 /* kind of the exported package: 0 candidates, 1 full */, SV_NOK1 = 52 /* 1: no (more) full packages for this column */,
+       SV_CUP = 53 /* the committer has been seen running */, SV_PPFL = 55 /* the frontier (threshold) the last pre-pass ran at */, SV_K1STAMP = 54 /* a full package is only exported beyond this frontier (the stamp of one that was sent back) */,
        SV_PKGVER = 60 /* version of this worker's exported package (0: none yet) */, SV_PKGX = 61 /* 1: exported and still valid */,
        SV_PKGF = 62 /* the frontier the package's positions were read at */ };
 #define SLIP_PP_WORDS  14
@@ -178,10 +185,16 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
 #define SLIP_PKG_STAMP0  18
 #define SLIP_PKG_VER     19       /* the version the sums belong to (every candidate record carries it too) */
 #define SLIP_PKG_WORKER  20       /* the exporting worker: its verdict goes to ITS mailbox (the slot may be reused by column k + nworkers before the worker has read it) */
-#define SLIP_MBOX_WORDS  32       /* a worker's mailbox, behind the package slots: the outcome words */
+#define SLIP_PKG_KIND    21       /* 0: candidates + the rows of the pattern (a late source sends it back); 1: FULL -- every non-pivotal row with its value */
+#define SLIP_PKG_NFULL   22       /* kind 1: rows carried */
+#define SLIP_PKG_FULLMAX 128      /* a full package carries at most this many non-pivotal rows ... */
+#define SLIP_ENG_ROWS    256      /* ... which late sources may fill up to this many in the committer's chain engine */
+#define SLIP_MIRROR_MAX  16384    /* the chain engine keeps pinv in LDS (16-bit): matrices up to this dimension */
+#define SLIP_MBOX_HDR    32       /* a worker's mailbox, behind the package slots: the outcome words, then (full packages) the rows handed back */
+#define SLIP_MBOX_WORDS  (SLIP_MBOX_HDR + 4 * SLIP_ENG_ROWS)
 #define SLIP_PKG_OUT     0        /* the outcome words, as offsets into the exporting worker's MAILBOX (P.pkg + nworkers * SLIP_PKG_WORDS + worker * SLIP_MBOX_WORDS) */
 #define SLIP_PKG_CAND    64       /* 6 words per candidate: table index, value (2), aux, position, version */
-#define SLIP_PKG_ROWS    160
+#define SLIP_PKG_ROWS    160      /* kind 0: the rows of the pattern; kind 1: four arrays of SLIP_PKG_FULLMAX words: row, value (2), sign | history */
 #define SLIP_PKG_WORDS   704
 
 SLIP_DEV int slip_sgn(int32_t slen) { return (slen > 0) - (slen < 0); }
@@ -1201,7 +1214,7 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
              * (the launch ends when the last workgroup leaves).  One wave looks at the stop word between its items. */
             if (P.in_factor && kind == 1) {
                 if (wave == nw - 1 && lane == 0 && (slip_ld_i64(&P.st->stop) >> 8) < (int64_t) sv[SV_K]) sv[SV_ABORT] = 1;
-                if (sv[SV_ABORT]) break;
+                if ((int) slip_bcast0_u32((uint32_t) sv[SV_ABORT])) break;      /* one lane's view for the whole wave */
             }
             const int e = slip_run_item_out(&P, kind, j, jn, k, m0, wl, t, b0, b1, b2);
             if (e && lane == 0) sv[SV_ERR] = e;

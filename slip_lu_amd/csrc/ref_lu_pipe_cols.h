@@ -9,9 +9,20 @@
 #define SLIP_TR(i) do { } while (0)
 #endif
 #define SLIPDEV_ABORTED 100                 /* internal to the kernel: this worker's column can never commit */
+#if defined(SLIP_EMULATE) && defined(SLIP_EMU_TRACE)
+#define SLIP_WHY(...) do { if (slip_tid() == 0) fprintf(stderr, __VA_ARGS__); } while (0)
+#else
+#define SLIP_WHY(...) do { } while (0)
+#endif
+/* an inconsistency names itself in the state the host prints (site 100 + n, the column, two values) */
+#define SLIP_SITE(n, a, b) do { if (slip_tid() == 0 && !st->dbg_who) { st->dbg_who = 100 + (n); st->dbg_k = k; st->dbg_a = (int32_t)(a); st->dbg_b = (int32_t)(b); } } while (0)
 
 /* the worker's side of the committer protocol (ref_lu_pipe_commit.h) */
-SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *lds, const int Fl);
+SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *lds, const int F0, const int Fl);
+SLIP_DEV void slip_export_full(const SlipParams &P, const int k, uint32_t *lds, const int F0, const int Fl);
+#ifndef SLIP_K1_NEAR
+#define SLIP_K1_NEAR 12                     /* a full package goes out when the frontier is within this many columns of the column */
+#endif
 SLIP_DEV void slip_retract_package(const SlipParams &P, const int k, volatile int32_t *sv);
 
 SLIP_DEV void slip_raise_stop(SlipState *st, int k, int status) { slip_agent_min_i64(&st->stop, ((int64_t) k << 8) | (int64_t) status); }
@@ -118,12 +129,23 @@ SLIP_DEV void slip_rlist_push(const SlipParams &P, volatile int32_t *sv, uint32_
  * when it is a candidate.  Called by all threads; barriers inside. */
 #define SLIP_PP_BIAS   (1 << 20)
 #define SLIP_PP_CAND   64               /* one candidate per lane of the committing wave */
+/* Two refinements on top of the bounds (round 3):
+ *  - class-S rows (one limb, never updated) all carry the SAME factor rho[k-1]: among them only the rows whose |a| equals
+ *    the smallest (largest) |a| can be the pivot -- an exact comparison, so a column usually lists one candidate;
+ *  - the FULL package (ref_lu_pipe_commit.h, chain engine): when every non-pivotal row is a one-limb value the whole
+ *    column state can travel to the committer.  Rows updated at an older column h are brought to level Fl-1 for that
+ *    copy (x * rho[Fl-1] / rho[h], exact: the history update of slip_REF_triangular_solve.c:139-149 to an intermediate
+ *    level), so that the committer needs no pivot older than the package.  f_k0/f_k1: the value, f_meta: sign | h+1,
+ *    f_npi: the row's place among the non-pivotal (bit 31 clear) or among the pivotal rows (bit 31 set).
+ *    sv[SV_PPF] = number of non-pivotal rows, or -1 when some row does not qualify. */
 SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint32_t *lds, const int Fl)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane();
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     uint32_t *f_row = lds + SLIP_LDS_TAB, *f_pos = f_row + SLIP_TAB_CAP, *f_inf = f_row + 2 * SLIP_TAB_CAP, *f_aux = f_row + 3 * SLIP_TAB_CAP;
     uint32_t *f_k0 = lds + SLIP_LDS_KEYS, *f_k1 = f_k0 + SLIP_PAT_CAP;
+    uint32_t *f_meta = lds + SLIP_LDS_DIROFF, *f_npi = lds + SLIP_LDS_ROWS;
+    uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
     uint32_t *cl = lds + SLIP_LDS_WORK + SLIP_CAND_CAP;
     const int scheme = P.pivot_scheme;
     const int kind = (scheme == 4 || scheme == 5) ? 1 : 0;            /* 0 smallest, 1 largest (first-nonzero does not come here) */
@@ -131,32 +153,61 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
     const int col = P.q[k];
     const int nrows = sv[SV_NROWS];
     if (tid < SLIP_PP_WORDS) sv[SV_PP + tid] = tid == 11 && kind == 0 ? 0x7FFFFFFF : 0;
+    if (tid == SLIP_PP_WORDS) { sv[SV_PPF] = 0; sv[SV_TMP] = 0; sv[SV_TMP2] = 0; }
+    /* the full package is a possibility only with the engine running, a committed predecessor and room for the fill */
+    const bool want_full = P.engine && Fl >= 1 && nrows <= SLIP_TAB_CAP - SLIP_ENG_ROWS;
+    SlipPiv Mf = slip_piv_none();
+    if (want_full) Mf = slip_ld_piv(&P.piv[Fl - 1]);
+    const bool mf_small = want_full && slip_abs(Mf.len) <= 2;
     slip_block_sync();
     uint32_t ulimbs = 0, nUc = 0, sB = 0, nB = 0, maxcB = 0, maxzh = 0, maxc = 0, maxubp = 0;
     uint32_t best = kind == 0 ? 0x7FFFFFFFu : 0u;
+    uint64_t smin = ~0ull;                      /* smallest |a| (largest: its complement) over this thread's class-S rows */
+    int fullbad = mf_small ? 0 : 1;
     for (int t0 = 0; t0 < nrows; t0 += T) {
         const int t = t0 + tid;
-        int cls = 0, c = 0, isS = 0, r = 0; uint32_t asgn = 0;
+        int cls = 0, c = 0, isS = 0, r = 0, isU = 0, isNP = 0; uint32_t asgn = 0;
         if (t < nrows) {
             r = (int) f_row[t];
             const int pos = slip_ld_i32(&P.pinv[r]);
             const SlipRow xr = P.xrow[r];
             f_pos[t] = (uint32_t) pos;                      /* as read at a frontier >= Fl: the swap log brings it to column k */
-            if (pos < Fl) { ulimbs += (uint32_t) slip_limbs(xr.len); nUc++; if ((uint32_t) xr.bits > maxubp) maxubp = (uint32_t) xr.bits; }
-            else if (xr.len == 0) cls = 0;
+            if (pos < Fl) { isU = 1; ulimbs += (uint32_t) slip_limbs(xr.len); nUc++; if ((uint32_t) xr.bits > maxubp) maxubp = (uint32_t) xr.bits; }
+            else if (xr.len == 0) { cls = 0; isNP = 1; f_k0[t] = 0u; f_k1[t] = 0u; f_meta[t] = 0u; }      /* a zero keeps no history (slip_REF_triangular_solve.c:175-196 overwrites it) */
             else if (xr.h < 0 && slip_abs(xr.len) <= 2) {
-                cls = 2; isS = 1; c = xr.bits;
+                cls = 2; isS = 1; isNP = 1; c = xr.bits;
                 const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
                 f_k0[t] = (uint32_t) xv; f_k1[t] = (uint32_t)(xv >> 32);
+                f_meta[t] = xr.len < 0 ? 0x80000000u : 0u;
                 asgn = ((uint32_t) slip_abs(xr.len) << 12) | (xr.len < 0 ? 1u << 14 : 0u);
+                const uint64_t key = kind == 0 ? xv : ~xv;
+                if (key < smin) smin = key;
             } else {
-                cls = 3;
+                cls = 3; isNP = 1;
                 int bh = 0, zh = 0;
-                if (xr.h >= 0) { const SlipPiv H = slip_ld_piv(&P.piv[xr.h]); bh = H.bits; zh = H.ctz; }
+                SlipPiv H = slip_piv_none();
+                if (xr.h >= 0) { H = slip_ld_piv(&P.piv[xr.h]); bh = H.bits; zh = H.ctz; }
                 c = xr.bits - bh + (xr.h >= 0 ? 1 : 0);
                 sB += (uint32_t)(((c > 0 ? c : 0) + 63) >> 6) + 1u; nB++;
                 if ((uint32_t)(c + SLIP_PP_BIAS) > maxcB) maxcB = (uint32_t)(c + SLIP_PP_BIAS);
                 if ((uint32_t) zh > maxzh) maxzh = (uint32_t) zh;
+                /* the copy for a full package: a one-limb value, brought to level Fl-1 when it was updated before that */
+                if (mf_small) {
+                    int okf = slip_abs(xr.len) <= 2 && xr.h >= 0 && xr.h <= Fl - 1;
+                    if (okf) {
+                        const uint64_t xv = slip_limb0(P.xd + (int64_t) r * P.xcap);
+                        slip_u128 y = (slip_u128) xv; int ys = slip_sgn(xr.len), hh = xr.h;
+                        if (xr.h < Fl - 1) {
+                            if (slip_abs(H.len) <= 2 && xr.bits + Mf.bits <= 126) {
+                                y = slip_divexact128((slip_u128) xv * Mf.lo, H.lo, H.ctz, H.inv64);
+                                ys *= slip_sgn(Mf.len) * slip_sgn(H.len); hh = Fl - 1;
+                            } else okf = 0;
+                        }
+                        if (okf && (uint64_t)(y >> 64) != 0) okf = 0;
+                        if (okf) { f_k0[t] = (uint32_t)(uint64_t) y; f_k1[t] = (uint32_t)((uint64_t) y >> 32); f_meta[t] = (ys < 0 ? 0x80000000u : 0u) | (uint32_t)(hh + 1); }
+                    }
+                    if (!okf) fullbad = 1;
+                }
             }
         }
         /* S rows get their slots in the L slab now (slot index kept in the row's own x area, behind the value) */
@@ -168,6 +219,19 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
             const int si = abase + slip_popc64(am & ((1ull << lane) - 1ull));
             f_aux[t] = (uint32_t) si | asgn;
             (P.xd + (int64_t) r * P.xcap)[2] = (uint32_t) si;
+        }
+        /* places among the non-pivotal and among the pivotal rows (full packages; what the worker rebuilds its lists from) */
+        if (want_full) {
+            const uint64_t nm = slip_ballot(isNP), um = slip_ballot(isU);
+            int nb_ = 0, ub_ = 0;
+            if (lane == 0) {
+                if (nm) nb_ = slip_atomic_add_i32((int32_t *) &sv[SV_TMP], slip_popc64(nm));
+                if (um) ub_ = slip_atomic_add_i32((int32_t *) &sv[SV_TMP2], slip_popc64(um));
+            }
+            nb_ = (int) slip_bcast0_u32((uint32_t) nb_); ub_ = (int) slip_bcast0_u32((uint32_t) ub_);
+            const uint64_t below = (1ull << lane) - 1ull;
+            if (isNP) f_npi[t] = (uint32_t)(nb_ + slip_popc64(nm & below));
+            else if (isU) f_npi[t] = 0x80000000u | (uint32_t)(ub_ + slip_popc64(um & below));
         }
         if (t < nrows) {
             f_inf[t] = (uint32_t) cls | ((uint32_t)(c + SLIP_PP_BIAS) << 2);
@@ -182,15 +246,17 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
         const uint32_t w_u = slip_wave_sum_u32(ulimbs), w_n = slip_wave_sum_u32(nUc), w_s = slip_wave_sum_u32(sB), w_nb = slip_wave_sum_u32(nB);
         const uint32_t w_cb = slip_wave_max_u32(maxcB), w_zh = slip_wave_max_u32(maxzh), w_c = slip_wave_max_u32(maxc), w_up = slip_wave_max_u32(maxubp);
         const uint32_t w_b = kind == 0 ? slip_wave_min_u32(best) : slip_wave_max_u32(best);
+        const uint32_t w_fb = slip_wave_max_u32((uint32_t) fullbad);
         if (lane == 0) {
             if (w_n) { slip_atomic_add_i32((int32_t *) &sv[SV_PP + 3], (int) w_n); slip_atomic_add_i32((int32_t *) &sv[SV_PP + 4], (int) w_u); }
             if (w_nb) { slip_atomic_add_i32((int32_t *) &sv[SV_PP + 5], (int) w_s); slip_atomic_add_i32((int32_t *) &sv[SV_PP + 6], (int) w_nb); }
             slip_atomic_max_i32((int32_t *) &sv[SV_PP + 7], (int) w_cb); slip_atomic_max_i32((int32_t *) &sv[SV_PP + 8], (int) w_zh);
             slip_atomic_max_i32((int32_t *) &sv[SV_PP + 9], (int) w_c); slip_atomic_max_i32((int32_t *) &sv[SV_PP + 10], (int) w_up);
             if (kind == 0) slip_atomic_min_i32((int32_t *) &sv[SV_PP + 11], (int) w_b); else slip_atomic_max_i32((int32_t *) &sv[SV_PP + 11], (int) w_b);
+            if (w_fb) slip_atomic_max_i32((int32_t *) &sv[SV_PPF], 1);
         }
     }
-    slip_block_sync();
+    const uint64_t sbest = slip_block_min_u64(smin, scan_tmp);       /* barriers inside: the sums above are complete behind it */
     const uint32_t bestb = (uint32_t) sv[SV_PP + 11];
     const int any = sv[SV_PP + 9] != 0;                            /* a nonzero non-pivotal row exists */
     for (int t0 = 0; t0 < nrows && any; t0 += T) {
@@ -202,6 +268,10 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
             if (cls) {
                 const uint32_t ubc = inf >> 2, lbc = ubc - (cls == 2 ? 1u : 2u);
                 cand = kind == 0 ? lbc <= bestb : ubc >= bestb;
+                if (cand && cls == 2) {                     /* the exact test among the rows that share rho[k-1] as their only factor */
+                    const uint64_t xv = (uint64_t) f_k0[t] | ((uint64_t) f_k1[t] << 32);
+                    cand = (kind == 0 ? xv : ~xv) == sbest;
+                }
                 if (diagpref && (int) f_row[t] == col) { cand = 1; sv[SV_PP + 13] = t + 1; }
                 if (cand && cls != 2) sv[SV_PP + 12] = 1;
             }
@@ -213,7 +283,11 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
         if (cand) { const int at = bC + slip_popc64(mC & ((1ull << lane) - 1ull)); if (at < SLIP_PP_CAND) cl[at] = (uint32_t) t; }
     }
     slip_block_sync();
-    if (tid == 0) sv[SV_PP] = any && sv[SV_PP + 1] >= 1 && sv[SV_PP + 1] <= SLIP_PP_CAND;
+    if (tid == 0) {
+        sv[SV_PP] = any && sv[SV_PP + 1] >= 1 && sv[SV_PP + 1] <= SLIP_PP_CAND;
+        sv[SV_PPF] = (want_full && !sv[SV_PPF]) ? sv[SV_TMP] : -1;
+        sv[SV_PPFL] = Fl;
+    }
     slip_block_sync();
 }
 
@@ -229,12 +303,14 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
 template <bool FAST, bool GATED>
 SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const int tag, uint32_t *lds, uint32_t *bm, dig_t *b0, dig_t *b1, dig_t *b2,
                         unsigned long long &c_read, unsigned long long &c_upd, unsigned long long &c_src, unsigned long long &c_str,
-                        unsigned long long &c_mac, unsigned long long *t_wait, unsigned long long *t_last)
+                        unsigned long long &c_mac, unsigned long long *t_wait, unsigned long long *t_last, int *cur_io = (int *) 0)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave();
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     uint32_t *work = lds + SLIP_LDS_WORK;
-    int cur = -1, step = 0;
+    /* cur_io: where a sweep that parked on a full package (return 2) is taken up again when the package comes back */
+    int cur = cur_io ? *cur_io : -1, step = 0;
+    if (cur_io) { slip_block_sync(); if (tid == 0) { sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; } }      /* the rotating queue counters start over with step 0 */
     (void) t_wait; (void) t_last;
     /* the pre-pass of the commit chain runs when the sweep is dry and the frontier has not moved (slip_prepass) */
     const bool pp_want = GATED && k >= 1 && !P.no_early && P.pivot_scheme != 2 && slip_nwaves() >= 2;
@@ -265,25 +341,52 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
             int Fn;
             /* still dry: the exported package holds for every pivot below the frontier this worker knows */
             if (GATED && pp_fresh && tid == 0 && sv[SV_PKGX]) slip_st_u32(P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_STAMP, (uint32_t) Fl);
-            if (pp_want && !pp_fresh && sv[SV_NROWS] <= SLIP_TAB_CAP) {
-                Fn = slip_wait_frontier(st, lds, Fl + 1, k, 1);
-                if (Fn >= 0 && Fn <= Fl) {       /* nothing to do but wait: classify the rows and list the pivot candidates meanwhile */
-                    slip_prepass(P, k, tag, lds, Fl);
-                    pp_fresh = 1;
-                    /* a column whose candidates are all one-limb values is handed to the committer */
+            Fn = -2;
+            if (pp_want && sv[SV_NROWS] <= SLIP_TAB_CAP) {
+                if (!pp_fresh) {
+                    Fn = slip_wait_frontier(st, lds, Fl + 1, k, 1);
+                    if (Fn >= 0 && Fn <= Fl) {       /* nothing to do but wait: classify the rows and list the pivot candidates meanwhile */
+                        slip_prepass(P, k, tag, lds, Fl);
+                        pp_fresh = 1;
 #ifdef SLIP_EMU_TRACE
-                    if (tid == 0) fprintf(stderr, "worker: col %d prepass valid %d ncand %d nonS %d nrows %d committer %d\n", k, (int) sv[SV_PP], (int) sv[SV_PP + 1], (int) sv[SV_PP + 12], (int) sv[SV_NROWS], P.committer);
+                        if (tid == 0) fprintf(stderr, "worker: col %d prepass valid %d ncand %d nonS %d nrows %d full %d committer %d\n", k, (int) sv[SV_PP], (int) sv[SV_PP + 1], (int) sv[SV_PP + 12], (int) sv[SV_NROWS], (int) sv[SV_PPF], P.committer);
 #endif
-                    if (P.committer && sv[SV_PP] && !sv[SV_PP + 12] && sv[SV_PKGVER] < 120 && k < (1 << 24) - 1 && sv[SV_NROWS] <= SLIP_PKG_NROWMAX && sv[SV_PP + 1] <= SLIP_PKG_CANDS) {
-                        if (tid == 0) sv[SV_PKGF] = Fl;
-                        slip_export_package(P, k, lds, Fl);
+                        Fn = -2;
+                    }
+                }
+                if (pp_fresh && Fn == -2 && P.committer && !sv[SV_PKGX]) {
+                    /* packages go out only once the committer workgroup has been seen running (a launch whose block 0 is not
+                     * resident yet must not wait for it: those columns are committed by their workers) */
+                    {
+                        const int up_ = sv[SV_CUP];
+                        slip_block_sync();                   /* every thread has read the flag before thread 0 may set it */
+                        if (!up_) { if (tid == 0) sv[SV_CUP] = slip_ld_i32(&st->committer_up); slip_block_sync(); }
+                    }
+                    const bool can_pkg = sv[SV_CUP] && sv[SV_PKGVER] < 120 && k < (1 << 24) - 1;
+                    /* every non-pivotal row a one-limb value: the FULL package -- the committer's chain engine applies whatever
+                     * sources arrive after this frontier itself and hands the finished rows back (ref_lu_pipe_commit.h); this
+                     * worker parks until then.  It goes out when the column's turn is NEAR: the engine is one workgroup, every source
+                     * applied by the workers while they are far from their turn is work done in parallel. */
+                    const bool k1_ok = P.engine && sv[SV_PPF] >= 1 && sv[SV_PPF] <= SLIP_PKG_FULLMAX && !sv[SV_NOK1] && sv[SV_PPFL] > sv[SV_K1STAMP];
+                    if (can_pkg && k1_ok) {
+                        if (k - Fl <= SLIP_K1_NEAR) {
+                            if (tid == 0) { sv[SV_PKGF] = sv[SV_PPFL]; if (sv[SV_PKGVER]) slip_agent_add_u64(&st->c_retract, 1ull << 32); }
+                            slip_export_full(P, k, lds, sv[SV_PPFL], Fl);
+#ifdef SLIP_PROFILING
+                            if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 1] = (int32_t) slip_realtime();  /* time line 1: package exported */
+#endif
+                            if (cur_io) { *cur_io = cur; return 2; }
+                        }
+                    } else if (can_pkg && sv[SV_PP] && !sv[SV_PP + 12] && sv[SV_NROWS] <= SLIP_PKG_NROWMAX && sv[SV_PP + 1] <= SLIP_PKG_CANDS) {
+                        /* a column whose candidates are all one-limb values is handed to the committer */
+                        if (tid == 0) { sv[SV_PKGF] = sv[SV_PPFL]; if (sv[SV_PKGVER]) slip_agent_add_u64(&st->c_retract, 1ull << 32); }
+                        slip_export_package(P, k, lds, sv[SV_PPFL], Fl);
 #ifdef SLIP_PROFILING
                         if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 1] = (int32_t) slip_realtime();  /* time line 1: package exported */
 #endif
                     }
-                    Fn = -2;
                 }
-            } else Fn = -2;
+            }
             /* the wait proper; a worker that waits helps with the long update queues of others (slip_farm_help) */
             while (Fn <= -2) {
                 Fn = slip_wait_frontier(st, lds, Fl + 1, k, 0, &P);
@@ -326,7 +429,36 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
             continue;
         }
         cur = jn;
-        if (GATED && pp_fresh) { pp_fresh = 0; if (tid == 0) { sv[SV_PP] = 0; if (sv[SV_PKGX]) slip_retract_package(P, k, sv); } }      /* this source changes the rows */
+        /* this source changes the rows: what the pre-pass found no longer holds (also after this sweep was taken up again behind a
+         * full package that came back: pp_fresh is per call, the flags are the column's) */
+        if (GATED) { pp_fresh = 0; if (tid == 0 && (sv[SV_PP] || sv[SV_PKGX])) { sv[SV_PP] = 0; if (sv[SV_PKGX]) slip_retract_package(P, k, sv); } }
+        if (GATED && jn >= sv[SV_F2] && P.engine && pp_want && cur_io && !sv[SV_NOK1] && k - Fl <= SLIP_K1_NEAR && jn >= 1 && jn > sv[SV_K1STAMP]      /* (a package of this column, if any, has just been retracted) */
+            && sv[SV_NROWS] <= SLIP_TAB_CAP) {
+            /* this column's turn is near and the next source's L column is not published yet (its worker is still in stage 2):
+             * rather than wait for it, hand the column to the chain engine with everything from position jn on still to be
+             * applied -- the engine has the recent L columns in its LDS */
+            slip_block_sync();
+            if (tid == 0) sv[SV_TMP2] = slip_agent_add_i32(&P.Lready[jn], 0) != 0;
+            slip_block_sync();
+            if (!sv[SV_TMP2]) {
+                {
+                    const int up_ = sv[SV_CUP];
+                    slip_block_sync();
+                    if (!up_) { if (tid == 0) sv[SV_CUP] = slip_ld_i32(&st->committer_up); slip_block_sync(); }
+                }
+                if (sv[SV_CUP] && sv[SV_PKGVER] < 120 && k < (1 << 24) - 1) {
+                    slip_prepass(P, k, tag, lds, jn);               /* rows at positions >= jn travel with their values */
+                    if (sv[SV_PPF] >= 1 && sv[SV_PPF] <= SLIP_PKG_FULLMAX) {
+                        if (tid == 0) { sv[SV_PKGF] = jn; sv[SV_PP] = 0; if (sv[SV_PKGVER]) slip_agent_add_u64(&st->c_retract, 1ull << 32); }
+                        slip_export_full(P, k, lds, jn, jn);
+                        *cur_io = jn - 1;                            /* taken up again AT this source should the package come back */
+                        return 2;
+                    }
+                    if (tid == 0) { sv[SV_NOK1] = 1; sv[SV_PP] = 0; }   /* a value the engine does not take: no further attempts for this column */
+                    slip_block_sync();
+                }
+            }
+        }
         if (GATED && jn >= sv[SV_F2]) {
             /* the source is committed but its L column may still be on its way (stage 2 of column jn) */
 #ifdef SLIP_PROFILING
@@ -520,6 +652,82 @@ SLIP_DEV int slip_publish_digits(dig_t *dst, const dig_t *src, int src_shared, i
     return ctz < 0 ? 0 : ctz;
 }
 
+/* Wait for the committer's verdict on this worker's exported package (its mailbox; not the frontier line).  Called by all
+ * threads; a waiting worker helps with open update queues.  Returns 1 committed, 0 sent back, -1 the column can never commit. */
+SLIP_DEV int slip_wait_verdict(const SlipParams &P, SlipState *st, uint32_t *lds, const int k, dig_t *b0, dig_t *b1, dig_t *b2)
+{
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    const uint32_t *pk = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;      /* this worker's mailbox */
+    for (;;) {
+        slip_block_sync();
+        if (slip_tid() == 0) {
+            int res; unsigned long long spins = 0;
+            for (;;) {
+                const int v = (int) slip_ld_u32(pk + SLIP_PKG_OUT), mine_ = (sv[SV_PKGVER] << 24) | (k + 1);      /* a verdict names the version it is about */
+                if (v == mine_) { res = 1; break; }
+                if (v == -mine_) { res = 0; break; }
+                const int64_t stop = slip_ld_i64(&st->stop);
+                if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
+                { const int h = slip_farm_peek(P, st, 1); if (h) { res = -1 - h; break; } }
+                slip_sleep_short();
+                if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 3; st->dbg_k = k; st->dbg_a = v; st->dbg_b = mine_; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
+            }
+            sv[SV_TMP2] = res;
+            if (res == 0) sv[SV_PKGX] = 0;               /* sent back: this worker carries on with the column itself */
+        }
+        slip_block_sync();
+        const int res = sv[SV_TMP2];
+        if (res <= -2) { slip_farm_help(P, st, lds, -res - 2, b0, b1, b2); continue; }
+        return res;
+    }
+}
+
+/* A FULL package has been committed by the chain engine: the mailbox holds every row that was non-pivotal when the package
+ * left, plus the rows later sources filled in, with their FINAL values (level k-1; a row that became pivotal meanwhile: its
+ * value as the U entry) and their positions at column k.  The worker's row lists become: its own pivotal rows (final
+ * since the export), then the rows handed back; the values go into its private x rows, so that the rest of the column
+ * (pattern, table, L / U stores) runs as after any other early commit.  Called by all threads. */
+SLIP_DEV void slip_takeover_full(const SlipParams &P, const int k, const int tag, uint32_t *lds, uint32_t *bm)
+{
+    const int tid = slip_tid(), T = slip_nthreads();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    uint32_t *f_row = lds + SLIP_LDS_TAB, *f_pos = f_row + SLIP_TAB_CAP;
+    const uint32_t *f_npi = lds + SLIP_LDS_ROWS;
+    uint32_t *t_row = lds + SLIP_LDS_KEYS, *t_pos = t_row + SLIP_PAT_CAP;
+    const uint32_t *mb = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;
+    const int nold = sv[SV_NROWS], nU = sv[SV_PP + 3];
+    const int nfin = (int) slip_ld_u32(mb + SLIP_PKG_OUT + 5);
+    slip_block_sync();
+    for (int t = tid; t < nold; t += T) {
+        const uint32_t pi = f_npi[t];
+        if (pi >> 31) { t_row[pi & 0x7FFFFFFFu] = f_row[t]; t_pos[pi & 0x7FFFFFFFu] = f_pos[t]; }
+    }
+    const uint32_t *hb = mb + SLIP_MBOX_HDR;
+    for (int t = tid; t < nfin; t += T) {
+        const uint32_t r = slip_ld_u32(hb + t), vlo = slip_ld_u32(hb + SLIP_ENG_ROWS + t), vhi = slip_ld_u32(hb + 2 * SLIP_ENG_ROWS + t);
+        const uint32_t me = slip_ld_u32(hb + 3 * SLIP_ENG_ROWS + t);
+        t_row[nU + t] = r; t_pos[nU + t] = me & 0xFFFFFFu;
+        const uint64_t mag = (uint64_t) vlo | ((uint64_t) vhi << 32);
+        slip_store_small(P, (int) r, (slip_u128) mag, (me >> 31) ? -1 : 1, k - 1, tag);
+    }
+    slip_block_sync();
+    const int nnew = nU + nfin;
+    for (int t = tid; t < nnew; t += T) {
+        const uint32_t r = t_row[t], pos = t_pos[t];
+        f_row[t] = r; f_pos[t] = pos; P.rlist[t] = (int) r; P.rpos[t] = (int) pos;
+        slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
+    }
+    if (tid == 0) sv[SV_NROWS] = nnew;
+#if defined(SLIP_EMULATE) && defined(SLIP_EMU_TRACE)
+    if (tid == 0) {
+        fprintf(stderr, "takeover col %d: stamp %d nold %d nU %d nfin %d:", k, (int) sv[SV_PKGF], nold, nU, nfin);
+        for (int t = 0; t < nnew; t++) fprintf(stderr, " %s%u@%u", t < nU ? "U" : "", t_row[t], t_pos[t]);
+        fprintf(stderr, "\n");
+    }
+#endif
+    slip_block_sync();
+}
+
 /* ------------------------------------------------------------------ */
 /* one column; returns a SLIPDEV_* status (0 = committed), SLIPDEV_ABORTED when the column must be dropped */
 /* ------------------------------------------------------------------ */
@@ -550,7 +758,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     /* ---- phase 0: clear the pattern bitmap, take a snapshot of the commit frontier ---- */
     for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
     if (tid == 0) {
-        sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv[SV_NROWS] = 0; sv[SV_ACNT] = 0; sv[SV_EST] = -1; sv[SV_PP] = 0; sv[SV_PKGX] = 0; sv[SV_PKGVER] = 0; sv[SV_ABORT] = 0;
+        sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_MAXDIG] = 0; sv[SV_NROWS] = 0; sv[SV_ACNT] = 0; sv[SV_EST] = -1; sv[SV_PP] = 0; sv[SV_PKGX] = 0; sv[SV_PKGVER] = 0; sv[SV_ABORT] = 0; sv[SV_PPF] = -1; sv[SV_PKGK] = 0; sv[SV_NOK1] = 0; sv[SV_K1STAMP] = 0;
         sv64[SV_LALLOC / 2] = 0; sv64[SV_LEXACT / 2] = 0;
         /* the ready frontier first: it never passes the commit frontier, also not between the two loads */
         sv[SV_F2] = slip_ld_i32(&st->F2);
@@ -594,9 +802,33 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
 #ifdef SLIP_PROFILING
     int32_t trs_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long trp_ = 0;
 #endif
-    if (slip_sweep<FAST, true>(P, st, k, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac, t_wait_, &t_last_)) return SLIPDEV_ABORTED;
+    int full_adopt = 0;
+    {
+        int sweep_at = -1;
+        for (;;) {
+            const int sr = slip_sweep<FAST, true>(P, st, k, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac, t_wait_, &t_last_, &sweep_at);
+            if (sr == 1) return SLIPDEV_ABORTED;
+            if (sr != 2) break;
+            /* parked on a full package: the chain engine commits the column from it, or sends it back */
+            const int v = slip_wait_verdict(P, st, lds, k, b0, b1, b2);
+#ifdef SLIP_PROFILING
+            if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 3] = (int32_t) slip_realtime();      /* time line 3: verdict seen */
+#endif
+            if (v < 0) return SLIPDEV_ABORTED;
+            if (v == 1) { full_adopt = 1; break; }
+            if (tid == 0) {
+                /* sent back: for good (a value the engine does not handle), or until this worker has applied the source
+                 * the engine could not (its column was committed elsewhere): the next full package must be a later one */
+                const uint32_t *mb_ = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;
+                if (slip_ld_u32(mb_ + SLIP_PKG_OUT + 1) != 1u) sv[SV_NOK1] = 1;
+                sv[SV_K1STAMP] = sv[SV_PKGF];
+            }
+            slip_block_sync();
+        }
+    }
+    if (full_adopt) slip_takeover_full(P, k, tag, lds, bm);
     slip_block_sync();
-    if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
+    if (sv[SV_ERR]) { if (sv[SV_ERR] >= 6 && sv[SV_ERR] != SLIPDEV_ABORTED) SLIP_SITE(11, sv[SV_ERR], 0); return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X; }
     SLIP_STAMP(1);
 #ifdef SLIP_PROFILING
     trp_ = t_last_ ? t_last_ : slip_clock(); SLIP_TR(0);        /* 0: sweep tail */
@@ -631,33 +863,16 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     /* a heavy column: the wall-clock time of every phase stamp (tools/phase_probe.py prints them) */
     if (nrows > 400 && tid == 0) { hstamp_ = P.dbg + 24 * (int64_t) P.n + 32 * (int64_t)(k & 63); for (int q_ = 0; q_ < 32; q_++) hstamp_[q_] = 0; hstamp_[31] = k; hstamp_[30] = nrows; hstamp_[29] = (int32_t) slip_realtime(); }
 #endif
-    const int packaged = P.committer && try_early && sv[SV_PKGX];
+    const int packaged = !full_adopt && P.committer && try_early && sv[SV_PKGX];
     slip_block_sync();                                   /* (thread 0 clears the flag below) */
-    if (packaged) for (;;) {
-        const uint32_t *pk = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;      /* this worker's mailbox */
-        if (tid == 0) {
-            int res; unsigned long long spins = 0;
-            for (;;) {
-                const int v = (int) slip_ld_u32(pk + SLIP_PKG_OUT), mine_ = (sv[SV_PKGVER] << 24) | (k + 1);      /* a verdict names the version it is about */
-                if (v == mine_) { res = 1; break; }
-                if (v == -mine_) { res = 0; break; }
-                const int64_t stop = slip_ld_i64(&st->stop);
-                if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
-                { const int h = slip_farm_peek(P, st, 1); if (h) { res = -1 - h; break; } }
-                slip_sleep_short();
-                if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 3; st->dbg_k = k; st->dbg_a = v; st->dbg_b = mine_; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
-            }
-            sv[SV_TMP2] = res;
-            if (res == 0) sv[SV_PKGX] = 0;               /* rejected: this worker commits the column itself */
-        }
-        slip_block_sync();
-        if (sv[SV_TMP2] <= -2) { const int slot_ = -sv[SV_TMP2] - 2; slip_farm_help(P, st, lds, slot_, b0, b1, b2); continue; }
+    if (full_adopt) adopted = 1;
+    if (packaged) {
+        const int v = slip_wait_verdict(P, st, lds, k, b0, b1, b2);
 #ifdef SLIP_PROFILING
         if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 3] = (int32_t) slip_realtime();      /* time line 3: verdict seen */
 #endif
-        if (sv[SV_TMP2] < 0) return SLIPDEV_ABORTED;
-        adopted = sv[SV_TMP2];
-        break;
+        if (v < 0) return SLIPDEV_ABORTED;
+        adopted = v;
     }
     const bool fastc = !adopted && try_early && nw >= 2 && sv[SV_PP] != 0;
     uint32_t *ppcl = work + SLIP_CAND_CAP;                 /* the pre-pass's candidate list (table indices) */
@@ -783,7 +998,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                     if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && f_pos[tt] < f_pos[bt])) bt = tt;
                 }
             }
-            if (bt < 0) { est = SLIPDEV_INTERNAL; bt = 0; }
+            if (bt < 0) { est = SLIPDEV_INTERNAL; bt = 0; if (lane == 0 && !st->dbg_who) { st->dbg_who = 109; st->dbg_k = k; st->dbg_a = A.ncand; } }
             e_pivrow = (int) f_row[bt]; e_pivpos = (int) f_pos[bt];
             int stg = (int)((f_inf[bt] >> 26) & 31u) - 1;     /* LDS slot of the pivot's digits, or -1 */
             /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); col's value is exact: it was a candidate */
@@ -872,7 +1087,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         /* the position snapshot (pinv as the reference has it at column k): the value the pre-pass read at frontier stamp0, or
          * where the LAST swap in [stamp0, k) that displaced the row put it (positions of non-pivotal rows only ever grow, and a
          * value read late already shows the swaps before it).  The log goes through LDS in pieces. */
-        {
+        if (!full_adopt) {                               /* (a full package comes back with the positions at column k) */
             const int stamp0 = sv[SV_PKGF];
             uint32_t *lg_row = lds + SLIP_LDS_KEYS, *lg_pos = lg_row + SLIP_PAT_CAP;
             int myr[4] = {-1, -1, -1, -1}, myp[4] = {0, 0, 0, 0};      /* SLIP_PKG_NROWMAX rows over at least 128 threads */
@@ -999,7 +1214,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 const CommitArgs ca = { ncand, diag_cand, nA, nLc, ncA + ncB, slotw, 1, nUc_all, U_l, Lb_total, Lnz_, Lnl_, Unz_, Unl_, ppcl };
                 search_publish(ca);
             } else {
-                if (lane == 0) sv[SV_EST] = ok ? SLIPDEV_INTERNAL : -1;      /* the bounds said this could not happen / the full pass */
+                if (lane == 0) { sv[SV_EST] = ok ? SLIPDEV_INTERNAL : -1; if (ok && !st->dbg_who) { st->dbg_who = 110; st->dbg_k = k; st->dbg_a = sv[SV_ERR]; } }      /* the bounds said this could not happen / the full pass */
                 slip_block_sync_named(1);
             }
             if (lane == 0 && ok && !sv[SV_EST]) slip_agent_add_u64(&st->c_short, 1ull);
@@ -1228,7 +1443,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             }
             slip_block_sync();
             if (ncB > 0) slip_drain(P, lds, 2, 0, 0, k, 0, ncB, wlB, b0, b1, b2);
-            if (sv[SV_ERR]) return SLIPDEV_INTERNAL;          /* the bounds said this could not happen */
+            if (sv[SV_ERR]) { SLIP_SITE(1, sv[SV_ERR], 0); return SLIPDEV_INTERNAL; }          /* the bounds said this could not happen */
             SLIP_STAMP(22);                                   /* early: candidate lists and arithmetic */
             SLIP_TR(5);                                       /* 5: candidate multiplies + barrier */
             if (wave == 0) {
@@ -1261,7 +1476,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     uint32_t *diroff = lds + SLIP_LDS_DIROFF;
     auto row_at = [&](int t) -> int { return npat <= SLIP_PAT_CAP ? rowl[t] : P.srow[t]; };
     slip_block_sync();
-    if (npat != nrows) return early ? SLIPDEV_INTERNAL : SLIPDEV_INTERNAL;      /* every discovered row has exactly one position */
+    if (npat != nrows) { SLIP_SITE(2, npat, nrows | (full_adopt << 16) | (adopted << 17) | (early << 18)); SLIP_WHY("col %d: npat %d != nrows %d (early %d full %d)\n", k, npat, nrows, early, full_adopt); return SLIPDEV_INTERNAL; }      /* every discovered row has exactly one position */
     for (int t = tid; t < nrows; t += T) {
         const int r = small ? (int) f_row[t] : P.rlist[t];
         const int pos = small ? (int) f_pos[t] : P.rpos[t];
@@ -1387,7 +1602,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             slip_block_sync();
         }
     }
-    if (sv[SV_ERR]) return (early || sv[SV_ERR] >= 6) ? SLIPDEV_INTERNAL : SLIPDEV_GROW_X;    /* after an early commit nothing may fail */
+    if (sv[SV_ERR]) { if (early || sv[SV_ERR] >= 6) SLIP_SITE(3, sv[SV_ERR], early); SLIP_WHY("col %d: error %d in the history phase (early %d)\n", k, (int) sv[SV_ERR], early); return (early || sv[SV_ERR] >= 6) ? SLIPDEV_INTERNAL : SLIPDEV_GROW_X; }    /* after an early commit nothing may fail */
     SLIP_STAMP(3);
 
     /* ---- phase 5: column-window cap, then the pivot search ---- */
@@ -1447,7 +1662,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         for (int t = tid; t < nL; t += T) if (ent_row(nU + t) == e_pivrow) sv[SV_TMP] = t;
         slip_block_sync();
         best = sv[SV_TMP];
-        if (best < 0) return SLIPDEV_INTERNAL;
+        if (best < 0) { SLIP_SITE(4, e_pivrow, nL); SLIP_WHY("col %d: pivot row %d not in the L part\n", k, e_pivrow); return SLIPDEV_INTERNAL; }
     } else if (kind != 2 && maxdig < (1 << 18)) {
         /* one pass: (bit length, leading 40 bits) packed into one key; the candidates that share the best key are
          * compared exactly, ties towards the earlier pattern position (slip_get_smallest_pivot.c:79) */
@@ -1585,9 +1800,9 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     }
     const uint64_t totU = baseU, totL = lalloc + baseL;         /* limbs of slab consumed by this column */
     const uint64_t totLexact = baseL + dirL;
-    if (Unz + nUe > P.Ucap_nz || Unl + (int64_t) totU > P.Ucap_nl) return early ? SLIPDEV_INTERNAL : SLIPDEV_GROW_U;
-    if (Lnz + nL > P.Lcap_nz || Lnl + (int64_t) totL > P.Lcap_nl) return early ? SLIPDEV_INTERNAL : SLIPDEV_GROW_L;
-    if (early && (Lnl + (int64_t) totL > slip_ld_i64(&P.Lo[k + 1]) || Unl + (int64_t) totU != slip_ld_i64(&P.Uo[k + 1]))) return SLIPDEV_INTERNAL;   /* the published bounds hold */
+    if (Unz + nUe > P.Ucap_nz || Unl + (int64_t) totU > P.Ucap_nl) { if (early) SLIP_SITE(5, nUe, totU); return early ? SLIPDEV_INTERNAL : SLIPDEV_GROW_U; }
+    if (Lnz + nL > P.Lcap_nz || Lnl + (int64_t) totL > P.Lcap_nl) { if (early) SLIP_SITE(6, nL, totL); return early ? SLIPDEV_INTERNAL : SLIPDEV_GROW_L; }
+    if (early && (Lnl + (int64_t) totL > slip_ld_i64(&P.Lo[k + 1]) || Unl + (int64_t) totU != slip_ld_i64(&P.Uo[k + 1]))) { SLIP_SITE(7 + full_adopt, (Lnl + (int64_t) totL) - slip_ld_i64(&P.Lo[k + 1]), (Unl + (int64_t) totU) - slip_ld_i64(&P.Uo[k + 1])); SLIP_WHY("col %d: bounds: L %lld + %lld vs %lld, U %lld + %lld vs %lld (full %d)\n", k, (long long) Lnl, (long long) totL, (long long) slip_ld_i64(&P.Lo[k + 1]), (long long) Unl, (long long) totU, (long long) slip_ld_i64(&P.Uo[k + 1]), full_adopt); return SLIPDEV_INTERNAL; }   /* the published bounds hold */
     /* the pivot's record fields, read before the permutation swap below changes what row_perm answers */
     const int32_t plen = ent_len(pividx);
     const int pbits = ent_bits(pividx);
@@ -1718,6 +1933,7 @@ SLIP_DEV void slip_factor_worker(const SlipParams &P, SlipState *st, uint32_t *l
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
     unsigned long long acc[5] = {0, 0, 0, 0, 0};
+    if (tid == 0) sv[SV_CUP] = 0;                /* the committer has not been seen yet */
     for (;;) {
         slip_block_sync();
         if (tid == 0) {

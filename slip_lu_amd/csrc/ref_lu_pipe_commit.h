@@ -1,38 +1,89 @@
 /* ref_lu_pipe_commit.h -- the committer: ONE workgroup of the launch that runs the commit chain of the column loop.
  *
  * The commit chain (choose the pivot of column k, publish rho_k and the row swap: slip_get_pivot.c:30-183 inside
- * SLIP_LU_factorize.c:190-264) is the serial part of the factorisation: column k's pivot search needs rho_{k-1}.  When
- * every column worker runs its own commit, each hop of the chain crosses the chip: the frontier word, rho_{k-1}'s record
- * and digits travel through memory, and the worker executes code that left its instruction cache milliseconds ago.  A
- * column whose rows were not touched by the last sources does not need any of that: what the pivot choice needs except
- * rho_{k-1} is known long before (slip_prepass) and fits a small PACKAGE: the pivot candidates (one-limb values never
- * updated, class S) and a few sums for the capacity checks.  The workers export such packages; the committer -- block 0,
- * a persistent loop over a few hundred instructions that stay in its instruction cache, with rho_{k-1}'s digits and the
- * slab cursors still in its LDS from the previous column -- multiplies the candidates, searches, applies the diagonal
- * rule, publishes stage 1 and moves the frontier; the worker is told the outcome and carries on with the bulk of its column
- * (pattern, remaining rows, L/U stores) as after its own early commit.  Columns without a valid package (a source arrived
- * late, long candidates, bounds too close to a capacity) are committed by their worker as before: the committer sees the
- * frontier pass and resynchronises.
+ * SLIP_LU_factorize.c:190-264) is the serial part of the factorisation: columns commit in order, and column k's values
+ * need rho_{k-1}.  When every column worker runs its own commit, each hop of the chain crosses the chip.  The workers
+ * therefore export PACKAGES, and the committer -- block 0, a persistent loop with rho_{k-1}, the slab cursors, the last
+ * 512 swaps and pivots in its LDS -- commits them without leaving its CU.  Two kinds of package:
  *
- * Package of column k: slot k % nworkers of P.pkg, SLIP_PKG_WORDS words:
- *   HDR   64-bit {k+1, version}; version odd: being written or retracted (seqlock: the committer reads the header, the
- *         package, and the header again)
- *   STAMP the frontier the worker has checked its rows against (none of row_perm[c], c < stamp, is a non-pivotal row of the
- *         package); the committer checks [stamp, k) itself
- *   SUMS  sv[SV_PP ..] of the pre-pass;  CAND 4 words per candidate: table index, value (2 words), aux (slot, digits, sign)
- *   ROWS  the rows of the pattern in discovery order;  POS their positions (pinv) at column k, written BY THE COMMITTER
- *   OUT   the outcome, written by the committer, polled by the worker: state k+1 committed / -(k+1) rejected, pivot row,
- *         its position, signed length, bits, slab offset, limbs handed out in the slab
- * The committer never writes into a worker's private memory and never stores a candidate's product in the slab (the worker
- * recomputes the few candidates with the rest of its rows): only the pivot's digits, its record, the swap, the column
- * pointers, the positions and the outcome leave the committer, all written through and drained before the frontier moves. */
+ *   kind 0 (candidates): a column whose pivot candidates are one-limb values that were never updated (class S).  All of
+ *     them carry the same factor rho_{k-1}, so the pivot choice (slip_get_smallest_pivot.c:25-101: smallest |x|, ties by
+ *     pattern position; the tolerance rule of slip_get_pivot.c:89-118) is decided on the one-limb values themselves; only
+ *     the pivot's product a * rho_{k-1} is formed (it is rho_k).  A source that arrives after the export sends the package back.
+ *
+ *   kind 1 (FULL, round 3): a short column whose non-pivotal rows are all one-limb values travels with its whole state
+ *     (row, value, sign, history level).  The committer's CHAIN ENGINE keeps pinv mirrored in LDS (16 bit, n <= 16384)
+ *     and the L columns it has committed this way in an LDS ring, so it applies the sources that arrived after the export
+ *     ITSELF (slip_REF_triangular_solve.c:124-241 in one-limb arithmetic, fill included), brings the rows to level k-1
+ *     (:248-257), searches, commits, and hands the finished rows with their positions back to the worker, which only
+ *     sorts and stores them (stage 2).  A run of short dependent columns is thereby committed without a single hop
+ *     across the chip; anything the engine cannot do exactly in 64-bit values (or a source whose column is not in its
+ *     ring) sends the package back and the worker carries on as before.
+ *
+ * Per batch of up to SLIP_CB columns: (a) wave 0 polls the headers; (b) one round of loads brings the packages into LDS
+ * (one wave per column); (c) wave 0 alone commits the columns one after the other on LDS only and leaves a publish record
+ * per column; (d) the waves issue the stage-1 stores of the columns side by side; (e) one drain, the verdicts, the frontier.
+ *
+ * Package of column k: slot k % nworkers of P.pkg (offsets SLIP_PKG_* in ref_lu_pipe.h); the header is a seqlock
+ * {k+1, version} (odd: being written / retracted), read before and after the contents.  The outcome goes to the
+ * exporting worker's MAILBOX: verdict word {version, +-(k+1)}, pivot row, position, length, bits, slab offset, limbs
+ * handed out; for a full package also the rows handed back.  Everything the committer stores for other workgroups is
+ * written through (sc1) and drained before the verdicts and the frontier. */
 #ifndef SLIP_REF_LU_PIPE_COMMIT_H
 #define SLIP_REF_LU_PIPE_COMMIT_H
 
+#ifndef SLIP_CB
+#define SLIP_CB          8                  /* columns per batch */
+#endif
+#define SLIP_CB_RING     512                /* swaps and pivots the committer remembers (more than the columns in flight) */
+#define SLIP_CBW         640                /* one batch column in LDS: 32 header words, 96 candidate words, 512 row words */
+#define SLIP_CB_SLOTW    264                /* rho_j: a product of a one-limb value and a pivot of at most 256 digits, whole limbs */
+#define SLIP_LRING       3072               /* entries of the engine's ring of L columns (3 words each) */
+#define SLIP_PUBW        32
+
+/* where the committer keeps what in its LDS (words from lds + SLIP_LDS_WORK); the host sizes the launch with it */
+struct SlipCommitLayout {
+    int cbuf, pub, stage, ring_row, ring_disp, ring_opos, pr_lo0, pr_lo1, pr_inv0, pr_inv1, pr_meta, ld_start, ld_cnt, ld_col, lring,
+        est_row, est_vlo, est_vhi, est_meta, est_hash, misc, Ms, scr, pinvm, total;
+};
+#define SLIP_COMMIT_SCR  272                /* digits per scratch buffer of the exact tolerance comparison (pivots up to 256 digits) */
+static inline
+#if !defined(SLIP_EMULATE)
+__host__ __device__
+#endif
+SlipCommitLayout slip_commit_layout(int n, int engine)
+{
+    SlipCommitLayout L; int o = 0;
+    L.cbuf = o; o += SLIP_CB * SLIP_CBW;
+    L.pub = o; o += SLIP_CB * SLIP_PUBW;
+    L.stage = o; o += SLIP_CB * SLIP_CB_SLOTW;
+    L.ring_row = o; o += SLIP_CB_RING; L.ring_disp = o; o += SLIP_CB_RING; L.ring_opos = o; o += SLIP_CB_RING;
+    L.pr_lo0 = o; o += SLIP_CB_RING; L.pr_lo1 = o; o += SLIP_CB_RING; L.pr_inv0 = o; o += SLIP_CB_RING; L.pr_inv1 = o; o += SLIP_CB_RING;
+    L.pr_meta = o; o += SLIP_CB_RING;
+    L.ld_start = o; o += SLIP_CB_RING; L.ld_cnt = o; o += SLIP_CB_RING; L.ld_col = o; o += SLIP_CB_RING;
+    L.lring = o; o += engine ? 3 * SLIP_LRING : 0;
+    L.est_row = o; o += engine ? SLIP_ENG_ROWS : 0; L.est_vlo = o; o += engine ? SLIP_ENG_ROWS : 0;
+    L.est_vhi = o; o += engine ? SLIP_ENG_ROWS : 0; L.est_meta = o; o += engine ? SLIP_ENG_ROWS : 0;
+    L.est_hash = o; o += engine ? 512 : 0;
+    L.misc = o; o += 192;
+    L.Ms = o; o += SLIP_CB_SLOTW;
+    L.scr = o; o += 3 * SLIP_COMMIT_SCR;
+    L.pinvm = o; o += engine ? (n + 1) / 2 : 0;
+    L.total = o;
+    return L;
+}
+/* dynamic LDS words a launch with a committer needs at least */
+static inline
+#if !defined(SLIP_EMULATE)
+__host__ __device__
+#endif
+int slip_commit_lds_words(int n, int engine) { return SLIP_LDS_WORK + slip_commit_layout(n, engine).total + 8; }
+
 /* the worker's side: export the package the pre-pass has just prepared (all threads; barriers inside).  A column may
  * export again after a retraction: the version in the header, in the sums and in every candidate record tells the
- * committer which package it is looking at (it reads header and contents in separate rounds of loads). */
-SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *lds, const int Fl)
+ * committer which package it is looking at. */
+/* F0: the frontier the pre-pass ran at (positions, history levels); Fl: the frontier up to which the worker has checked its rows since */
+SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *lds, const int F0, const int Fl)
 {
     const int tid = slip_tid(), T = slip_nthreads();
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
@@ -53,15 +104,53 @@ SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *ld
     }
     if (tid < SLIP_PP_WORDS) slip_st_u32(pk + SLIP_PKG_SUMS + tid, (uint32_t) sv[SV_PP + tid]);
     if (tid == SLIP_PP_WORDS) {
-        slip_st_u32(pk + SLIP_PKG_STAMP, (uint32_t) Fl); slip_st_u32(pk + SLIP_PKG_STAMP0, (uint32_t) Fl);
+        slip_st_u32(pk + SLIP_PKG_STAMP, (uint32_t) Fl); slip_st_u32(pk + SLIP_PKG_STAMP0, (uint32_t) F0);
         slip_st_u32(pk + SLIP_PKG_NROWS, (uint32_t) nrows); slip_st_u32(pk + SLIP_PKG_VER, ver); slip_st_u32(pk + SLIP_PKG_WORKER, (uint32_t) P.worker);
+        slip_st_u32(pk + SLIP_PKG_KIND, 0u); slip_st_u32(pk + SLIP_PKG_NFULL, 0u);
         slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS + SLIP_PKG_OUT, 0u);
     }
     slip_vm_drain();
     slip_block_sync();
     if (tid == 0) {
         slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t) ver << 32) | (uint32_t)(k + 1));
-        sv[SV_PKGVER] = (int32_t) ver; sv[SV_PKGX] = 1;
+        sv[SV_PKGVER] = (int32_t) ver; sv[SV_PKGX] = 1; sv[SV_PKGK] = 0;
+    }
+    slip_block_sync();
+}
+
+/* the worker's side: a FULL package -- every non-pivotal row with its one-limb value, sign and history level as the
+ * pre-pass left them (slip_prepass: f_k0/f_k1, f_meta, places f_npi).  All threads; barriers inside. */
+SLIP_DEV void slip_export_full(const SlipParams &P, const int k, uint32_t *lds, const int F0, const int Fl)
+{
+    const int tid = slip_tid(), T = slip_nthreads();
+    volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
+    const uint32_t *f_row = lds + SLIP_LDS_TAB;
+    const uint32_t *f_k0 = lds + SLIP_LDS_KEYS, *f_k1 = f_k0 + SLIP_PAT_CAP;
+    const uint32_t *f_meta = lds + SLIP_LDS_DIROFF, *f_npi = lds + SLIP_LDS_ROWS;
+    uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
+    const int nrows = sv[SV_NROWS], nnp = sv[SV_PPF];
+    const uint32_t ver = ((uint32_t) sv[SV_PKGVER] | 1u) + 1u;
+    if (tid == 0) { slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t)(ver - 1u) << 32) | (uint32_t)(k + 1)); slip_vm_drain(); }
+    slip_block_sync();
+    for (int t = tid; t < nrows; t += T) {
+        const uint32_t pi = f_npi[t];
+        if (pi >> 31) continue;                                 /* pivotal: final, stays with the worker */
+        uint32_t *a = pk + SLIP_PKG_ROWS + pi;
+        slip_st_u32(a, f_row[t]); slip_st_u32(a + SLIP_PKG_FULLMAX, f_k0[t]); slip_st_u32(a + 2 * SLIP_PKG_FULLMAX, f_k1[t]);
+        slip_st_u32(a + 3 * SLIP_PKG_FULLMAX, f_meta[t]);
+    }
+    if (tid < SLIP_PP_WORDS) slip_st_u32(pk + SLIP_PKG_SUMS + tid, (uint32_t) sv[SV_PP + tid]);
+    if (tid == SLIP_PP_WORDS) {
+        slip_st_u32(pk + SLIP_PKG_STAMP, (uint32_t) Fl); slip_st_u32(pk + SLIP_PKG_STAMP0, (uint32_t) F0);
+        slip_st_u32(pk + SLIP_PKG_NROWS, (uint32_t) nrows); slip_st_u32(pk + SLIP_PKG_VER, ver); slip_st_u32(pk + SLIP_PKG_WORKER, (uint32_t) P.worker);
+        slip_st_u32(pk + SLIP_PKG_KIND, 1u); slip_st_u32(pk + SLIP_PKG_NFULL, (uint32_t) nnp);
+        slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS + SLIP_PKG_OUT, 0u);
+    }
+    slip_vm_drain();
+    slip_block_sync();
+    if (tid == 0) {
+        slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t) ver << 32) | (uint32_t)(k + 1));
+        sv[SV_PKGVER] = (int32_t) ver; sv[SV_PKGX] = 1; sv[SV_PKGK] = 1;
     }
     slip_block_sync();
 }
@@ -73,6 +162,7 @@ SLIP_DEV void slip_retract_package(const SlipParams &P, const int k, volatile in
     const uint32_t ver = (uint32_t) sv[SV_PKGVER] | 1u;
     slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t) ver << 32) | (uint32_t)(k + 1));
     sv[SV_PKGVER] = (int32_t) ver; sv[SV_PKGX] = 0;
+    slip_agent_add_u64(&P.st->c_retract, 1ull);
 }
 
 /* one candidate: the one-limb value a (nd digits) times rho[k-1] (in registers) -> LDS slot, search key, length */
@@ -100,45 +190,88 @@ template <int D> SLIP_DEV void slip_commit_mul(const WR<D> &Mr, uint32_t a0, uin
     *key_out = key; *len_out = len;
 }
 
-/* LDS of the committer, words from lds + SLIP_LDS_WORK (the lists, tables and keys of a column worker: 12288 words) */
-#ifndef SLIP_CB
-#define SLIP_CB          8                  /* columns per batch */
-#endif
-#define SLIP_CB_RING     512                /* swaps the committer remembers (more than the columns in flight) */
-#define SLIP_CBW         (32 + 6 * SLIP_PKG_CANDS + SLIP_PKG_NROWMAX)      /* one batch column: sums, candidates, rows */
-#define SLIP_CB_SLOTW    262                /* a product of a one-limb value and a pivot of at most 256 digits, whole limbs */
+SLIP_DEV int slip_bits64(uint64_t v) { return v ? 64 - slip_clz64(v) : 0; }
 
-/* the kernel body of the committer (block 0 of a launch with P.committer set).
- * Per batch: (a) wave 0 polls the headers of the next SLIP_CB columns; (b) one round of loads brings the ready packages
- * into LDS, every wave checks one column's rows against the pivots its worker has not seen; (c) wave 0 alone, on LDS
- * only, commits the columns one after the other: rows against the pivots of this batch, capacity checks, candidates'
- * positions from the swaps it remembers, products, search, diagonal rule, stage-1 stores ISSUED (not waited for);
- * (d) one drain, then the outcomes and the frontier. */
+/* is  num * 2^(-te) >= tol_m * den ?  (the tolerance rule of slip_get_pivot.c:89-118 on one-limb magnitudes; tol_m has
+ * exactly 53 bits).  1 / 0, or -1 when the comparison does not fit 128 bits */
+SLIP_DEV int slip_tol_small(uint64_t tol_m, int te, uint64_t num, uint64_t den)
+{
+    const int sa = te < 0 ? -te : 0, sb = te > 0 ? te : 0;
+    const int bn = slip_bits64(num) + sa, bd = slip_bits64(den) + sb;
+    if (bn < 52 + bd) return 0;
+    if (bn > 53 + bd) return 1;
+    if (bn > 126 || bd + 53 > 126) return -1;
+    const slip_u128 lhs = (slip_u128) num << sa, rhs = ((slip_u128) tol_m * den) << sb;
+    return lhs >= rhs ? 1 : 0;
+}
+
+/* a pivot of the committer's ring: one-limb pivots keep what the in-lane arithmetic needs */
+struct SlipSmallPiv { uint64_t lo, inv; int ctz, sgn, small, bits; };
+
+/* the kernel body of the committer (block 0 of a launch with P.committer set) */
 template <bool FAST>
 SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
-    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     volatile int64_t *sv64 = (volatile int64_t *)(lds + SLIP_LDS_VARS);
+    const SlipCommitLayout Ly = slip_commit_layout(P.n, P.engine);
     uint32_t *base = lds + SLIP_LDS_WORK;
-    dig_t *stage = base + SLIP_CB * SLIP_CBW;
-    uint32_t *ring_row = stage + SLIP_PKG_CANDS * SLIP_CB_SLOTW, *ring_disp = ring_row + SLIP_CB_RING, *ring_opos = ring_disp + SLIP_CB_RING;
-    uint32_t *ck0 = ring_opos + SLIP_CB_RING, *ck1 = ck0 + SLIP_PKG_CANDS, *clen = ck1 + SLIP_PKG_CANDS, *cpos = clen + SLIP_PKG_CANDS;
-    const int wcap = P.wcap;
-    dig_t *b0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap : P.gscratch + (int64_t) wave * 3 * wcap;
-    dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
-    dig_t *Ms = lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + nw * 3 * wcap;      /* rho[j-1]'s digits (the committer runs with LDS scratch only) */
-    SlipPiv *Mrec = (SlipPiv *)(lds + SLIP_LDS_SCAN);            /* rho[j-1]'s record */
+    uint32_t *cbuf = base + Ly.cbuf, *pub = base + Ly.pub;
+    dig_t *stage = base + Ly.stage;
+    uint32_t *ring_row = base + Ly.ring_row, *ring_disp = base + Ly.ring_disp, *ring_opos = base + Ly.ring_opos;
+    uint32_t *pr_lo0 = base + Ly.pr_lo0, *pr_lo1 = base + Ly.pr_lo1, *pr_inv0 = base + Ly.pr_inv0, *pr_inv1 = base + Ly.pr_inv1, *pr_meta = base + Ly.pr_meta;
+    uint32_t *ld_start = base + Ly.ld_start, *ld_cnt = base + Ly.ld_cnt, *ld_col = base + Ly.ld_col, *lring = base + Ly.lring;
+    uint32_t *est_row = base + Ly.est_row, *est_vlo = base + Ly.est_vlo, *est_vhi = base + Ly.est_vhi, *est_meta = base + Ly.est_meta, *est_hash = base + Ly.est_hash;
+    uint32_t *misc = base + Ly.misc;
+    uint32_t *ck_pos = misc, *hver = misc + 64;                     /* candidate positions; the versions of the batch's packages as the poll saw them */
+    unsigned long long *eacc = (unsigned long long *)(misc + 128);  /* the engine's algorithmic counters (8 x 64 bit) */
+    dig_t *Ms = base + Ly.Ms;                                       /* rho[j-1]'s digits */
+    dig_t *b0 = base + Ly.scr, *b1 = b0 + SLIP_COMMIT_SCR, *b2 = b1 + SLIP_COMMIT_SCR;
+    uint16_t *pinvm = (uint16_t *)(base + Ly.pinvm);                /* engine: pinv as it stands at the column being committed */
+    SlipPiv *Mrec = (SlipPiv *)(lds + SLIP_LDS_SCAN);               /* rho[j-1]'s record */
+    const int wcap = SLIP_COMMIT_SCR;
     const int scheme = P.pivot_scheme;
     const int kind = (scheme == 4 || scheme == 5) ? 1 : 0;
-    enum { C_K = SV_PP + SLIP_PP_WORDS, C_HAVE, C_GO, C_RING0, C_REJ, C_REJV, C_ST, C_LASTPR, C_IM2 };
-    uint32_t *hver = cpos + SLIP_PKG_CANDS;                      /* the versions of the batch's packages as the poll saw them */
+    const int diagpref = scheme == 1 || scheme == 3 || scheme == 4;
+    const bool mirror = P.engine != 0;
+    enum { C_K = SV_PP + SLIP_PP_WORDS, C_HAVE, C_GO, C_RING0, C_REJ, C_REJV, C_ST, C_LASTPR, C_NBC, C_LW, C_PR0 };
+    const uint32_t BIG = 0x7FFFFFFFu;
+    /* ring entry of pivot c for the in-lane arithmetic */
+    auto pring_get = [&](int c) -> SlipSmallPiv {
+        const int s_ = c & (SLIP_CB_RING - 1);
+        SlipSmallPiv p; const uint32_t m = pr_meta[s_];
+        p.lo = (uint64_t) pr_lo0[s_] | ((uint64_t) pr_lo1[s_] << 32); p.inv = (uint64_t) pr_inv0[s_] | ((uint64_t) pr_inv1[s_] << 32);
+        p.ctz = (int)(m & 0xFFu); p.sgn = (m >> 8) & 1u ? -1 : 1; p.small = (int)((m >> 9) & 1u); p.bits = (int)(m >> 16);
+        return p;
+    };
+    auto pring_put = [&](int c, const SlipPiv &pv) {                 /* one lane */
+        const int s_ = c & (SLIP_CB_RING - 1);
+        const int small = slip_abs(pv.len) <= 2 && pv.len != 0;
+        pr_lo0[s_] = (uint32_t) pv.lo; pr_lo1[s_] = (uint32_t)(pv.lo >> 32); pr_inv0[s_] = (uint32_t) pv.inv64; pr_inv1[s_] = (uint32_t)(pv.inv64 >> 32);
+        pr_meta[s_] = (uint32_t)(pv.ctz & 0xFF) | (pv.len < 0 ? 0x100u : 0u) | (small ? 0x200u : 0u) | ((uint32_t)(small ? pv.bits : 0) << 16);
+    };
+    auto hslot = [&](uint32_t row) -> uint32_t { return (row * 2654435761u) >> 23; };        /* 9 bits */
+    auto est_lookup = [&](uint32_t row) -> int {
+        uint32_t s_ = hslot(row);
+        for (int p_ = 0; p_ < 512; p_++) { const uint32_t e = est_hash[s_]; if (e == 0u) return -1; if ((e >> 8) == row + 1u) return (int)(e & 255u); s_ = (s_ + 1u) & 511u; }
+        return -1;
+    };
+    auto est_insert = [&](uint32_t row, int idx) {
+        uint32_t s_ = hslot(row); const uint32_t v = ((row + 1u) << 8) | (uint32_t) idx;
+        for (int p_ = 0; p_ < 512; p_++) { if (slip_atomic_cas_u32(&est_hash[s_], 0u, v) == 0u) break; s_ = (s_ + 1u) & 511u; }
+    };
+
     if (tid == 0) {
-        int pr_; sv[C_K] = slip_ld_frontier(st, &pr_);
-        sv[C_HAVE] = 0; sv[C_RING0] = sv[C_K]; sv[C_REJ] = -1; sv[C_REJV] = 0;
+        int pr_; const int F0 = slip_ld_frontier(st, &pr_);
+        sv[C_K] = F0; sv[C_HAVE] = 0; sv[C_RING0] = F0; sv[C_REJ] = -1; sv[C_REJV] = 0; sv[C_LW] = 0; sv[C_PR0] = F0;
+        for (int q = 0; q < 8; q++) eacc[q] = 0ull;
+        if (F0 >= 1) { const SlipPiv pv = slip_ld_piv(&P.piv[F0 - 1]); pring_put(F0 - 1, pv); sv[C_PR0] = F0 - 1; }
     }
+    for (int w = tid; w < SLIP_CB_RING; w += T) { ld_col[w] = 0xFFFFFFFFu; ld_cnt[w] = 0xFFFFFFFFu; }
+    if (mirror) for (int i = tid; i < P.n; i += T) pinvm[i] = (uint16_t) slip_ld_i32(&P.pinv[i]);
     slip_block_sync();
+    if (tid == 0) slip_agent_store_i32(&st->committer_up, 1);       /* from now on packages are answered */
 #ifdef SLIP_PROFILE_COMMIT
     unsigned long long tq_ = slip_realtime(), tacc_[24] = {0};
 #define SLIP_CT(i) do { if (tid == 0) { const unsigned long long n_ = slip_realtime(); tacc_[i] += n_ - tq_; tq_ = n_; } } while (0)
@@ -161,13 +294,31 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 slip_wave_sync_lds();
                 const int kc = sv[C_K];
                 if (kc > kprev) {
-                    /* columns committed by their workers: their swaps from the log every publisher keeps */
-                    for (int c = (kc - kprev > SLIP_CB_RING ? kc - SLIP_CB_RING : kprev) + lane; c < kc; c += SLIP_WAVE) {
+                    /* columns committed by their workers: their swaps from the log every publisher keeps, their pivots */
+                    const int lo_c = kc - kprev > SLIP_CB_RING ? kc - SLIP_CB_RING : kprev;
+                    for (int c = lo_c + lane; c < kc; c += SLIP_WAVE) {
                         ring_row[c & (SLIP_CB_RING - 1)] = (uint32_t) slip_ld_i32(&P.row_perm[c]);
                         ring_disp[c & (SLIP_CB_RING - 1)] = (uint32_t) slip_ld_i32(&P.sw_row[c]);
                         ring_opos[c & (SLIP_CB_RING - 1)] = (uint32_t) slip_ld_i32(&P.sw_pos[c]);
+                        const SlipPiv pv = slip_ld_piv(&P.piv[c]);
+                        pring_put(c, pv);
+                        ld_col[c & (SLIP_CB_RING - 1)] = 0xFFFFFFFFu;       /* its L column is not in the engine's ring */
                     }
-                    if (lane == 0 && kc - sv[C_RING0] > SLIP_CB_RING) sv[C_RING0] = kc - SLIP_CB_RING;
+                    slip_wave_sync_lds();
+                    if (mirror) {
+                        if (lo_c > kprev) { for (int i = lane; i < P.n; i += SLIP_WAVE) pinvm[i] = (uint16_t) slip_ld_i32(&P.pinv[i]); }     /* fell behind the ring: start over from memory (every swap below kc has landed) */
+                        else if (lane == 0) for (int c = kprev; c < kc; c++) {
+                            const int s_ = c & (SLIP_CB_RING - 1);
+#if defined(SLIP_EMULATE) && defined(SLIP_EMU_TRACE)
+                            fprintf(stderr, "resync col %d: pivot row %u, row %u to pos %u (mirror had %d / %d)\n", c, ring_row[s_], ring_disp[s_], ring_opos[s_], (int) pinvm[ring_row[s_]], (int) pinvm[ring_disp[s_]]);
+#endif
+                            pinvm[ring_row[s_]] = (uint16_t) c; pinvm[ring_disp[s_]] = (uint16_t) ring_opos[s_];
+                        }
+                    }
+                    if (lane == 0) {
+                        if (kc - sv[C_RING0] > SLIP_CB_RING) sv[C_RING0] = kc - SLIP_CB_RING;
+                        if (lo_c > kprev) sv[C_PR0] = lo_c; else if (kc - sv[C_PR0] > SLIP_CB_RING) sv[C_PR0] = kc - SLIP_CB_RING;
+                    }
                     slip_wave_sync_lds();
                 }
                 const int64_t stop = sv64[SV_LEXACT / 2];
@@ -191,11 +342,11 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         SLIP_CT(0);                                  /* 0: waiting for packages */
         const int kc = sv[C_K];
         const int have = sv[C_HAVE];
-        /* (b) the packages into LDS (one wave per column); what the previous batch did not leave behind */
+        /* (b) the packages into LDS (one wave per column) and what can be said about each by itself */
         for (int i = wave; i < nb; i += nw) {
             const int j = kc + i;
             const uint32_t *pk = P.pkg + (int64_t)(j % P.nworkers) * SLIP_PKG_WORDS;
-            uint32_t *cb = base + i * SLIP_CBW;
+            uint32_t *cb = cbuf + i * SLIP_CBW;
             if (lane < SLIP_PP_WORDS) cb[lane] = slip_ld_u32(pk + SLIP_PKG_SUMS + lane);
             else if (lane == 14) cb[14] = slip_ld_u32(pk + SLIP_PKG_STAMP);
             else if (lane == 15) cb[15] = slip_ld_u32(pk + SLIP_PKG_STAMP0);
@@ -204,8 +355,36 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             else if (lane == 18) cb[18] = 0u;
             else if (lane == 19) cb[19] = slip_ld_u32(pk + SLIP_PKG_VER);
             else if (lane == 20) cb[20] = slip_ld_u32(pk + SLIP_PKG_WORKER);
+            else if (lane == 21) cb[21] = slip_ld_u32(pk + SLIP_PKG_KIND);
+            else if (lane == 22) cb[22] = slip_ld_u32(pk + SLIP_PKG_NFULL);
             for (int c = lane; c < 6 * SLIP_PKG_CANDS; c += SLIP_WAVE) cb[32 + c] = slip_ld_u32(pk + SLIP_PKG_CAND + c);
-            for (int c = lane; c < SLIP_PKG_NROWMAX; c += SLIP_WAVE) cb[32 + 6 * SLIP_PKG_CANDS + c] = slip_ld_u32(pk + SLIP_PKG_ROWS + c);
+            for (int c = lane; c < 512; c += SLIP_WAVE) cb[128 + c] = slip_ld_u32(pk + SLIP_PKG_ROWS + c);
+            /* the header again, behind the contents (seqlock): a package that is being rewritten is offered again later */
+            const uint64_t h2 = slip_ld_u64((const uint64_t *)(pk + SLIP_PKG_HDR));
+            slip_wave_sync_lds();
+            const int kindp = (int) cb[21];
+            const int nrows = (int) cb[16], ncand = (int) cb[1], stamp = (int) cb[14], stamp0 = (int) cb[15];
+            int hit = (uint32_t) h2 != (uint32_t)(j + 1) || (uint32_t)(h2 >> 32) != hver[i] || cb[19] != hver[i] || cb[20] >= (uint32_t) P.nworkers
+                      || stamp < stamp0 || stamp > j || stamp0 < sv[C_RING0] || j - stamp0 > SLIP_CB_RING - SLIP_CB - 1;
+            if (kindp == 0) {
+                if (nrows < 1 || nrows > SLIP_PKG_NROWMAX || ncand < 1 || ncand > SLIP_PKG_CANDS || cb[12] != 0) hit = 1;
+                if (!hit && lane < ncand && cb[32 + 6 * lane + 5] != hver[i]) hit = 1;
+                if (!hit && !mirror) {
+                    /* the rows against the pivots its worker has not seen (those committed before this batch) */
+                    const uint32_t *rows = cb + 128;
+                    uint32_t rr[SLIP_PKG_NROWMAX / SLIP_WAVE];
+#pragma unroll
+                    for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) rr[q] = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
+                    for (int c = stamp; c < kc; c++) {
+                        const uint32_t r = ring_row[c & (SLIP_CB_RING - 1)];
+#pragma unroll
+                        for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) if (rr[q] == r) hit = 1;
+                    }
+                }
+            } else if (kindp == 1) {
+                if (!mirror || (int) cb[22] < 1 || (int) cb[22] > SLIP_PKG_FULLMAX || stamp0 < 1 || stamp0 - 1 < sv[C_PR0]) hit = 1;
+            } else hit = 1;
+            if (slip_ballot(hit) && lane == 0) cb[18] = 1u;
         }
         if (!have) {
             if (tid == T - 1) sv64[SV_LNZ / 2] = slip_ld_i64(&P.Lp[kc]);
@@ -219,109 +398,30 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         if (!have) {
             const SlipPiv M0 = *Mrec;
             const int l0 = slip_abs(M0.len);
-            if (l0 <= wcap) { const dig_t *Mg = slip_piv_digits(P, M0); for (int c = tid; c < l0; c += T) Ms[c] = slip_ld_u32(Mg + c); }
-        }
-        /* the rows of every batch column against the pivots its worker has not seen (those committed before this batch) */
-        for (int i = wave; i < nb; i += nw) {
-            const int j = kc + i;
-            uint32_t *cb = base + i * SLIP_CBW;
-            const int nrows = (int) cb[16], ncand = (int) cb[1], stamp = (int) cb[14], stamp0 = (int) cb[15];
-            int hit = nrows < 1 || nrows > SLIP_PKG_NROWMAX || ncand < 1 || ncand > SLIP_PKG_CANDS || stamp < stamp0 || stamp > j
-                      || stamp0 < sv[C_RING0] || j - stamp0 > SLIP_CB_RING - SLIP_CB || cb[12] != 0 || cb[19] != hver[i] || cb[20] >= (uint32_t) P.nworkers;
-            /* (a package being rewritten: its parts carry different versions -- it will be offered again) */
-            if (!hit && lane < ncand && cb[32 + 6 * lane + 5] != hver[i]) hit = 1;
-            if (!hit) {
-                const uint32_t *rows = cb + 32 + 6 * SLIP_PKG_CANDS;
-                uint32_t rr[SLIP_PKG_NROWMAX / SLIP_WAVE];
-#pragma unroll
-                for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) rr[q] = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
-                for (int c = stamp; c < kc; c++) {
-                    const uint32_t r = ring_row[c & (SLIP_CB_RING - 1)];
-#pragma unroll
-                    for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) if (rr[q] == r) hit = 1;
-                }
-            }
-            if (slip_ballot(hit) && lane == 0) cb[18] = 1u;
+            if (l0 <= SLIP_CB_SLOTW - 6) { const dig_t *Mg = slip_piv_digits(P, M0); for (int c = tid; c < l0; c += T) Ms[c] = slip_ld_u32(Mg + c); }
         }
         slip_block_sync();
-        SLIP_CT(2);                                  /* 2: rows against the known pivots (and rho after a resynchronisation) */
-        /* (c) the columns of the batch, one after the other, on LDS only: wave 0 prepares a column (rows against the pivots of
-         *     this batch, capacity checks, the candidates' positions), all waves multiply its candidates, wave 0 searches and
-         *     issues stage 1 */
-        int nbc = 0, rej = -1;
-        for (int i = 0; i < nb; i++) {
-            const int j = kc + i, col = P.q[j];
-            uint32_t *cb = base + i * SLIP_CBW;
-            const uint32_t *cands = cb + 32, *rows = cb + 32 + 6 * SLIP_PKG_CANDS;
-            uint32_t *pk = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t)(cb[20] < (uint32_t) P.nworkers ? cb[20] : 0u) * SLIP_MBOX_WORDS;     /* the worker's mailbox */
-            const int nrows = (int) cb[16], ncand = (int) cb[1], stamp0 = (int) cb[15];
-            const SlipPiv M = *Mrec;
-            const int lm = slip_abs(M.len), brho = M.bits, slot = (lm + 3) >> 1;
-            const int slotw = (lm + 5) & ~1;
-            const int nS = (int) cb[2], nB = (int) cb[6];
-            const uint32_t nUc_all = cb[3];
-            const uint64_t U_l = (uint64_t) cb[4];
-            const int64_t Lnz_ = sv64[SV_LNZ / 2], Lnl_ = sv64[SV_LNL / 2], Unz_ = sv64[SV_UNZ / 2], Unl_ = sv64[SV_UNL / 2];
-            const int nA = lm > 2 ? nS : 0;
-            const int maxc = (int) cb[9] - SLIP_PP_BIAS + brho;
-            const int maxub_all = maxc > (int) cb[10] ? maxc : (int) cb[10];
-            const uint64_t L_b = (uint64_t) cb[5] + (uint64_t) nB * (uint64_t)((brho + 63) >> 6) + (lm <= 2 ? 2ull * (uint64_t) nS : 0ull);
-            const uint64_t preserve = (uint64_t)((maxub_all + 63) >> 6) + 1;
-            const uint64_t Lb_total = (uint64_t) nA * (uint64_t) slot + preserve + L_b;
-            const uint64_t Ub_total = U_l + preserve;
-            const int nLc = nrows - (int) nUc_all;
-            if (wave == 0) {
-                int reject = (int) cb[18];
-                if (!reject && i > 0) {
-                    /* ... and against the pivots of this batch */
-                    int hit = 0;
-                    for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) {
-                        const uint32_t rq = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
-                        for (int c = kc; c < j; c++) if (ring_row[c & (SLIP_CB_RING - 1)] == rq) hit = 1;
-                    }
-                    if (slip_ballot(hit)) reject = 1;
-                }
-                if (!reject) {
-                    const bool A_ok = lm + 2 <= P.xcap && lm + 2 <= 256;
-                    if (lm > wcap || slotw > SLIP_CB_SLOTW || (lm > 2 && !A_ok)) reject = 2;
-                    if (nB > 0) {
-                        const int Wn = (((int) cb[7] - SLIP_PP_BIAS + brho + 31) >> 5) + (((int) cb[8] + 31) >> 5) + 1;
-                        if (Wn > P.wcap || Wn > P.xcap || Wn > P.invcap) reject = 2;
-                    }
-                    if (Lnz_ + nLc > P.Lcap_nz || Lnl_ + (int64_t) Lb_total > P.Lcap_nl) reject = 2;
-                    if (Unz_ + (int) nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t) Ub_total > P.Ucap_nl) reject = 2;
-                    if (P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) reject = 2;
-                }
-                if (!reject) {
-                    /* products of a one-limb pivot: in the lane */
-                    if (lm <= 2 && lane < ncand) {
-                        const uint64_t xv = (uint64_t) cands[6 * lane + 1] | ((uint64_t) cands[6 * lane + 2] << 32);
-                        const slip_u128 y = (slip_u128) xv * M.lo;
-                        const int yb = slip_bits128(y), yl = (yb + 31) >> 5;
-                        dig_t *sl = stage + lane * slotw;
-                        sl[0] = (uint32_t) y; sl[1] = (uint32_t)(y >> 32); sl[2] = (uint32_t)(y >> 64); sl[3] = (uint32_t)(y >> 96);
-                        const uint64_t top = yb ? (uint64_t)((y << (128 - yb)) >> 64) : 0ull;
-                        uint64_t key = ((uint64_t) yb << 40) | (top >> 24);
-                        if (kind == 1) key = ~key;
-                        ck0[lane] = (uint32_t) key; ck1[lane] = (uint32_t)(key >> 32); clen[lane] = (uint32_t) yl;
-                    }
-                }
-                if (lane == 0) sv[C_ST] = reject;
-            } else if (wave == 1) {
-                /* meanwhile, the second wave: the candidates' positions (pinv as the reference has it at column j) -- the value the
-                 * worker read at frontier stamp0, or where the LAST swap since then that displaced the row put it.  Lanes look
-                 * at the swaps, the candidates' rows come from the lanes that hold them. */
-                const uint32_t myrow = lane < ncand ? rows[cands[6 * lane]] : 0xFFFFFFFFu;
-                int last = -1;
-                for (int e0 = stamp0; e0 < j; e0 += SLIP_WAVE) {
-                    const int e = e0 + lane;
-                    const uint32_t d = e < j ? ring_disp[e & (SLIP_CB_RING - 1)] : 0xFFFFFFFEu;
-                    for (int c = 0; c < ncand; c++) {
-                        const uint64_t m = slip_ballot(d == slip_readlane(myrow, c));
-                        if (m && lane == c) last = e0 + 63 - slip_clz64(m);
-                    }
-                }
-                if (lane < ncand) cpos[lane] = last >= 0 ? ring_opos[last & (SLIP_CB_RING - 1)] : cands[6 * lane + 4];
+        SLIP_CT(2);                                  /* 2: rho after a resynchronisation */
+        /* (c) the columns of the batch, one after the other, by wave 0 on LDS only */
+        if (wave == 0) {
+            int nbc = 0, rej = -1;
+            for (int i = 0; i < nb; i++) {
+                const int j = kc + i, col = P.q[j];
+                uint32_t *cb = cbuf + i * SLIP_CBW;
+                uint32_t *pb = pub + i * SLIP_PUBW;
+                const uint32_t *cands = cb + 32, *rows = cb + 128;
+                uint32_t *mbx = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t)(cb[20] < (uint32_t) P.nworkers ? cb[20] : 0u) * SLIP_MBOX_WORDS;     /* the worker's mailbox */
+                const int nrows = (int) cb[16], ncand = (int) cb[1], stamp = (int) cb[14], stamp0 = (int) cb[15], kindp = (int) cb[21];
+                const SlipPiv M = *Mrec;
+                const int lm = slip_abs(M.len), brho = M.bits, slot = (lm + 3) >> 1;
+                const int slotw = (lm + 5) & ~1;
+                const int64_t Lnz_ = sv64[SV_LNZ / 2], Lnl_ = sv64[SV_LNL / 2], Unz_ = sv64[SV_UNZ / 2], Unl_ = sv64[SV_UNL / 2];
+                dig_t *sl = stage + i * SLIP_CB_SLOTW;
+                int reject = (int) cb[18];                      /* 1: offered again / the worker's business; 2: for good */
+                /* what both kinds leave for the publish step */
+                int e_pivrow = 0, e_pivpos = 0, lp_ = 0, pneg = 0, pbits = 0, nUc_all = 0, nLc = 0, nfin = 0, nlate = 0;
+                uint64_t U_l = 0, Lb_total = 0, plimbs = 0, lalloc = 0; int64_t poff = 0;
+                unsigned long long ec_src = 0, ec_read = 0, ec_str = 0, ec_upd = 0, ec_mac = 0;
                 /* the row at position j (the one the pivot changes places with): as loaded at the start of the batch, or the row a
                  * swap of this batch displaced to j */
                 int intermed2 = (int) cb[17];
@@ -330,164 +430,537 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     const uint64_t m = slip_ballot(e < j && (int) ring_opos[e & (SLIP_CB_RING - 1)] == j);
                     if (m) intermed2 = (int) ring_disp[(kc + 63 - slip_clz64(m)) & (SLIP_CB_RING - 1)];
                 }
-                if (lane == 0) sv[C_IM2] = intermed2;
-            }
-            SLIP_CT(10);
-            slip_block_sync();
-            SLIP_CT(11);
-            if (sv[C_ST]) { rej = j; break; }
-            /* products of a long pivot: one wave multiply per candidate with rho[j-1] in registers, the waves side by side */
-            if (lm > 2) {
-                const int Dm = (lm + 2 + 63) >> 6;
-                for (int c = wave; c < ncand; c += nw) {
-                    const uint32_t a0 = cands[6 * c + 1], a1 = cands[6 * c + 2]; const int nd = (int)((cands[6 * c + 3] >> 12) & 3u);
-                    uint64_t key; int len;
-                    if (Dm <= 1) slip_commit_mul<1>(wr_load<1>(Ms, lm), a0, a1, nd, stage + c * slotw, kind, &key, &len);
-                    else if (Dm == 2) slip_commit_mul<2>(wr_load<2>(Ms, lm), a0, a1, nd, stage + c * slotw, kind, &key, &len);
-                    else if (Dm == 3) slip_commit_mul<3>(wr_load<3>(Ms, lm), a0, a1, nd, stage + c * slotw, kind, &key, &len);
-                    else slip_commit_mul<4>(wr_load<4>(Ms, lm), a0, a1, nd, stage + c * slotw, kind, &key, &len);
-                    if (lane == 0) { ck0[c] = (uint32_t) key; ck1[c] = (uint32_t)(key >> 32); clen[c] = (uint32_t) len; }
-                }
-            }
-            SLIP_CT(12);
-            slip_block_sync();
-            SLIP_CT(13);
-            if (wave == 0) {
-                const int intermed2 = sv[C_IM2];
-                /* the search: (bit length, leading bits) keys; ties compared exactly, then by position (slip_get_smallest_pivot.c:79) */
-                const uint64_t mykey = lane < ncand ? ((uint64_t) ck0[lane] | ((uint64_t) ck1[lane] << 32)) : ~0ull;
-                const uint32_t mh = slip_wave_min_u32((uint32_t)(mykey >> 32));
-                const uint32_t ml = slip_wave_min_u32((uint32_t)(mykey >> 32) == mh ? (uint32_t) mykey : 0xFFFFFFFFu);
-                const uint64_t mk = ((uint64_t) mh << 32) | ml;
-                const int kbits = (int)((kind == 0 ? mk : ~mk) >> 40);
-                uint64_t tie = slip_ballot(lane < ncand && mykey == mk);
-                int bc = -1;
-                while (tie) {
-                    const int l = slip_ctz64(tie); tie &= tie - 1;
-                    if (bc < 0) { bc = l; continue; }
-                    int cmp = 0;
-                    if (kbits > 40) cmp = slip_cmp_mag(stage + bc * slotw, 0, stage + l * slotw, 0, (int) clen[l]);
-                    if ((kind == 0 && cmp > 0) || (kind == 1 && cmp < 0) || (cmp == 0 && cpos[l] < cpos[bc])) bc = l;
-                }
-                int est = bc < 0 ? SLIPDEV_INTERNAL : 0;
-                if (bc < 0) bc = 0;
-                /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); the worker listed the diagonal row when it is
-                 * a nonzero non-pivotal row of the pattern */
-                const int diag_t = (int) cb[13] - 1;
-                if (!est && (scheme == 1 || scheme == 3 || scheme == 4) && diag_t >= 0 && (int) cands[6 * bc] != diag_t) {
-                    const uint64_t dm = slip_ballot(lane < ncand && (int) cands[6 * lane] == diag_t);
-                    const int dc = dm ? slip_ctz64(dm) : -1;
-                    if (dc < 0) est = -1;                       /* not among the candidates it sent: the worker decides */
-                    else if (scheme == 1 || P.tol_mode == 0) bc = dc;
-                    else {
-                        const uint64_t kb_ = (uint64_t) ck0[bc] | ((uint64_t) ck1[bc] << 32), kd_ = (uint64_t) ck0[dc] | ((uint64_t) ck1[dc] << 32);
-                        const int kb = (int)((kind == 0 ? kb_ : ~kb_) >> 40), kd = (int)((kind == 0 ? kd_ : ~kd_) >> 40);
-                        const int te0 = P.tol_e;
-                        const int bnum_ = (scheme == 3 ? kb : kd) + (te0 < 0 ? -te0 : 0), bden_ = (scheme == 3 ? kd : kb) + (te0 > 0 ? te0 : 0);
-                        int take = 0;
-                        if (bnum_ < 52 + bden_) take = 0;
-                        else if (bnum_ > 53 + bden_) take = 1;
-                        else {
-                            const int cn = scheme == 3 ? bc : dc, cd = scheme == 3 ? dc : bc;
-                            const int ln = (int) clen[cn], ldn = (int) clen[cd];
-                            if (ldn + 2 > wcap) est = -1;
-                            else {
-                                const int tk = slip_tol_compare_out(P.tol_m, P.tol_e, stage + cn * slotw, ln, stage + cd * slotw, ldn, b0, b1, b2, wcap);
-                                if (tk < 0) est = -1; else take = tk;
-                            }
-                        }
-                        if (take) bc = dc;
-                    }
-                }
-                if (est) { if (est > 0 && lane == 0) slip_raise_stop(st, 0, SLIPDEV_INTERNAL); }
-                else {
-                    /* stage 1, issued and not waited for: the pivot's digits written through, its record, the swap and its log,
-                     * the column pointers, the outcome for the worker */
-                    const int e_pivrow = (int) rows[cands[6 * bc]], e_pivpos = (int) cpos[bc];
-                    const uint32_t ax = cands[6 * bc + 3];
-                    const int lp_ = (int) clen[bc];
-                    const int neg = (int)((ax >> 14) & 1u) ^ (M.len < 0);
-                    uint64_t key = (uint64_t) ck0[bc] | ((uint64_t) ck1[bc] << 32);
-                    if (kind == 1) key = ~key;
-                    const int pbits = (int)(key >> 40);
-                    const int64_t poff = lm > 2 ? Lnl_ + (int64_t)(ax & 0x3FFu) * slot : Lnl_ + (int64_t) nA * slot;
-                    const uint64_t plimbs = (uint64_t)((lp_ + 1) >> 1);
-                    const uint64_t lalloc = (uint64_t) nA * (uint64_t) slot + (lm > 2 ? 0ull : plimbs);
-                    const dig_t *src = stage + bc * slotw;
-                    const int z = slip_publish_digits((dig_t *)(P.Llimbs + poff), src, 0, lp_);
+                SLIP_CT(10);
+                if (!reject && kindp == 0) {
+                    /* ---- kind 0: candidates only ---- */
+                    const int nS = (int) cb[2], nB = (int) cb[6];
+                    nUc_all = (int) cb[3]; U_l = (uint64_t) cb[4];
+                    const int nA = lm > 2 ? nS : 0;
+                    const int maxc = (int) cb[9] - SLIP_PP_BIAS + brho;
+                    const int maxub_all = maxc > (int) cb[10] ? maxc : (int) cb[10];
+                    const uint64_t L_b = (uint64_t) cb[5] + (uint64_t) nB * (uint64_t)((brho + 63) >> 6) + (lm <= 2 ? 2ull * (uint64_t) nS : 0ull);
+                    const uint64_t preserve = (uint64_t)((maxub_all + 63) >> 6) + 1;
+                    Lb_total = (uint64_t) nA * (uint64_t) slot + preserve + L_b;
+                    const uint64_t Ub_total = U_l + preserve;
+                    nLc = nrows - nUc_all;
+                    /* a row of the pattern that has become pivotal since the worker looked: the package goes back */
                     {
-                        SlipPiv pr; pr.off = poff; pr.len = neg ? -lp_ : lp_; pr.bits = pbits; pr.ctz = z; pr.invlen = 0;
-                        pr.lo = *(const uint64_t *) src; pr.inv64 = 0; pr.pad = 0;
-                        if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
-                        const int64_t nUnz = Unz_ + (int) nUc_all + 1, nLnz = Lnz_ + nLc;
-                        const int64_t nUnl = Unl_ + (int64_t)(U_l + plimbs), nLnl = Lnl_ + (int64_t) Lb_total;
-                        /* every lane computes the same values; lane q issues store q: two store instructions instead of twenty-odd */
-                        {
-                            uint64_t *a8 = (uint64_t *) 0; uint64_t v8 = 0;
-                            uint64_t *pw = (uint64_t *) &P.piv[j];
-                            switch (lane) {
-                                case 0: a8 = pw; v8 = (uint64_t) pr.off; break;
-                                case 1: a8 = pw + 1; v8 = (uint64_t)(uint32_t) pr.len | ((uint64_t)(uint32_t) pr.bits << 32); break;
-                                case 2: a8 = pw + 2; v8 = pr.lo; break;
-                                case 3: a8 = pw + 3; v8 = (uint64_t)(uint32_t) pr.ctz; break;
-                                case 4: a8 = pw + 4; v8 = pr.inv64; break;
-                                case 5: a8 = (uint64_t *) &P.Up[j + 1]; v8 = (uint64_t) nUnz; break;
-                                case 6: a8 = (uint64_t *) &P.Lp[j + 1]; v8 = (uint64_t) nLnz; break;
-                                case 7: a8 = (uint64_t *) &P.Uo[j + 1]; v8 = (uint64_t) nUnl; break;
-                                case 8: a8 = (uint64_t *) &P.Lo[j + 1]; v8 = (uint64_t) nLnl; break;
-                                case 9: a8 = (uint64_t *)(pk + SLIP_PKG_OUT + 6); v8 = (uint64_t) poff; break;
-                                case 10: a8 = (uint64_t *)(pk + SLIP_PKG_OUT + 8); v8 = lalloc; break;
-                                default: break;
-                            }
-                            if (a8) slip_st_u64(a8, v8);
-                            uint32_t *a4 = (uint32_t *) 0; uint32_t v4 = 0;
-                            switch (lane) {
-                                case 0: a4 = (uint32_t *) &P.row_perm[j]; v4 = (uint32_t) e_pivrow; break;
-                                case 1: a4 = (uint32_t *) &P.row_perm[e_pivpos]; v4 = (uint32_t) intermed2; break;
-                                case 2: a4 = (uint32_t *) &P.pinv[e_pivrow]; v4 = (uint32_t) j; break;
-                                case 3: a4 = (uint32_t *) &P.pinv[intermed2]; v4 = (uint32_t) e_pivpos; break;
-                                case 4: a4 = (uint32_t *) &P.sw_row[j]; v4 = (uint32_t) intermed2; break;
-                                case 5: a4 = (uint32_t *) &P.sw_pos[j]; v4 = (uint32_t) e_pivpos; break;
-                                case 6: a4 = pk + SLIP_PKG_OUT + 1; v4 = (uint32_t) e_pivrow; break;
-                                case 7: a4 = pk + SLIP_PKG_OUT + 2; v4 = (uint32_t) e_pivpos; break;
-                                case 8: a4 = pk + SLIP_PKG_OUT + 3; v4 = (uint32_t)(neg ? -lp_ : lp_); break;
-                                case 9: a4 = pk + SLIP_PKG_OUT + 4; v4 = (uint32_t) pbits; break;
-                                default: break;
-                            }
-                            if (a4) slip_st_u32(a4, v4);
+                        int hit = 0;
+                        for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) {
+                            const int t = lane + 64 * q;
+                            if (t >= nrows) continue;
+                            const uint32_t rq = rows[t];
+                            if (mirror) { const int p = (int) pinvm[rq]; if (p >= stamp && p < j) hit = 1; }
+                            else for (int c = kc; c < j; c++) if (ring_row[c & (SLIP_CB_RING - 1)] == rq) hit = 1;
                         }
-                        if (lane == 0) {
-                            *Mrec = pr;
-                            sv64[SV_LNZ / 2] = nLnz; sv64[SV_LNL / 2] = nLnl; sv64[SV_UNZ / 2] = nUnz; sv64[SV_UNL / 2] = nUnl;
-                            ring_row[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivrow; ring_disp[j & (SLIP_CB_RING - 1)] = (uint32_t) intermed2;
-                            ring_opos[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivpos;
-                            if (j + 1 - sv[C_RING0] > SLIP_CB_RING) sv[C_RING0] = j + 1 - SLIP_CB_RING;
-                            sv[C_LASTPR] = e_pivrow;
+                        if (slip_ballot(hit)) reject = 1;
+                    }
+                    SLIP_CT(11);
+                    if (!reject) {
+                        const bool A_ok = lm + 2 <= P.xcap && lm + 2 <= 256;
+                        if (lm > SLIP_CB_SLOTW - 6 || slotw > SLIP_CB_SLOTW || (lm > 2 && !A_ok)) reject = 2;
+                        if (nB > 0) {
+                            const int Wn = (((int) cb[7] - SLIP_PP_BIAS + brho + 31) >> 5) + (((int) cb[8] + 31) >> 5) + 1;
+                            if (Wn > P.wcap || Wn > P.xcap || Wn > P.invcap) reject = 2;
+                        }
+                        if (Lnz_ + nLc > P.Lcap_nz || Lnl_ + (int64_t) Lb_total > P.Lcap_nl) reject = 2;
+                        if (Unz_ + nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t) Ub_total > P.Ucap_nl) reject = 2;
+                        if (P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) reject = 2;
+                    }
+                    SLIP_CT(12);
+                    int bc = 0;
+                    if (!reject) {
+                        /* the candidates are class-S values: a * rho[j-1] with the same rho for all, so |a| decides
+                         * (slip_get_smallest_pivot.c:58-101 / slip_get_largest_pivot.c); equal values by pattern position */
+                        const uint64_t av = lane < ncand ? ((uint64_t) cands[6 * lane + 1] | ((uint64_t) cands[6 * lane + 2] << 32)) : 0ull;
+                        const uint64_t mykey = lane < ncand ? (kind == 0 ? av : ~av) : ~0ull;
+                        const uint32_t mh = slip_wave_min_u32((uint32_t)(mykey >> 32));
+                        const uint32_t ml = slip_wave_min_u32((uint32_t)(mykey >> 32) == mh ? (uint32_t) mykey : 0xFFFFFFFFu);
+                        const uint64_t mk = ((uint64_t) mh << 32) | ml;
+                        const uint64_t tie = slip_ballot(lane < ncand && mykey == mk);
+                        /* the candidates' positions (pinv as the reference has it at column j): the mirror, or the value the worker read
+                         * at frontier stamp0 and where the LAST swap since then that displaced the row put it */
+                        uint32_t mypos = BIG;
+                        if (mirror) { if (lane < ncand) mypos = (uint32_t) pinvm[rows[cands[6 * lane]]]; }
+                        else {
+                            const uint32_t myrow = lane < ncand ? rows[cands[6 * lane]] : 0xFFFFFFFFu;
+                            int last = -1;
+                            for (int e0 = stamp0; e0 < j; e0 += SLIP_WAVE) {
+                                const int e = e0 + lane;
+                                const uint32_t d = e < j ? ring_disp[e & (SLIP_CB_RING - 1)] : 0xFFFFFFFEu;
+                                for (int c = 0; c < ncand; c++) {
+                                    const uint64_t m = slip_ballot(d == slip_readlane(myrow, c));
+                                    if (m && lane == c) last = e0 + 63 - slip_clz64(m);
+                                }
+                            }
+                            if (lane < ncand) mypos = last >= 0 ? ring_opos[last & (SLIP_CB_RING - 1)] : cands[6 * lane + 4];
+                        }
+                        if (lane < SLIP_PKG_CANDS) ck_pos[lane] = mypos;
+                        const uint32_t bp = slip_wave_min_u32(((tie >> lane) & 1ull) ? mypos : BIG);
+                        const uint64_t bm_ = slip_ballot(((tie >> lane) & 1ull) && mypos == bp);
+                        int est = bm_ ? 0 : SLIPDEV_INTERNAL;
+                        bc = bm_ ? slip_ctz64(bm_) : 0;
+                        /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); the worker listed the diagonal row when it is
+                         * a nonzero non-pivotal row of the pattern; the common factor rho[j-1] cancels in the ratio */
+                        const int diag_t = (int) cb[13] - 1;
+                        if (!est && diagpref && diag_t >= 0 && (int) cands[6 * bc] != diag_t) {
+                            const uint64_t dm = slip_ballot(lane < ncand && (int) cands[6 * lane] == diag_t);
+                            const int dc = dm ? slip_ctz64(dm) : -1;
+                            if (dc < 0) est = -1;                       /* not among the candidates it sent: the worker decides */
+                            else if (scheme == 1 || P.tol_mode == 0) bc = dc;
+                            else {
+                                const uint64_t ab = (uint64_t) cands[6 * bc + 1] | ((uint64_t) cands[6 * bc + 2] << 32), ad = (uint64_t) cands[6 * dc + 1] | ((uint64_t) cands[6 * dc + 2] << 32);
+                                const int tk = slip_tol_small(P.tol_m, P.tol_e, scheme == 3 ? ab : ad, scheme == 3 ? ad : ab);
+                                if (tk < 0) est = -1; else if (tk) bc = dc;
+                            }
+                        }
+                        if (est > 0) { if (lane == 0) { if (!st->dbg_who) { st->dbg_who = 120; st->dbg_k = j; st->dbg_a = ncand; st->dbg_b = (int32_t) tie; } slip_raise_stop(st, 0, SLIPDEV_INTERNAL); } reject = 2; }
+                        else if (est < 0) reject = 2;
+                    }
+                    SLIP_CT(13);
+                    if (!reject) {
+                        /* rho[j] = the pivot's one-limb value times rho[j-1] */
+                        const uint32_t a0 = cands[6 * bc + 1], a1 = cands[6 * bc + 2], ax = cands[6 * bc + 3];
+                        const int nd = (int)((ax >> 12) & 3u);
+                        if (lm <= 2) {
+                            const slip_u128 y = (slip_u128)((uint64_t) a0 | ((uint64_t) a1 << 32)) * M.lo;
+                            pbits = slip_bits128(y); lp_ = (pbits + 31) >> 5;
+                            if (lane == 0) { sl[0] = (uint32_t) y; sl[1] = (uint32_t)(y >> 32); sl[2] = (uint32_t)(y >> 64); sl[3] = (uint32_t)(y >> 96); }
+                        } else {
+                            const int Dm = (lm + 2 + 63) >> 6;
+                            uint64_t key; int len;
+                            if (Dm <= 1) slip_commit_mul<1>(wr_load<1>(Ms, lm), a0, a1, nd, sl, kind, &key, &len);
+                            else if (Dm == 2) slip_commit_mul<2>(wr_load<2>(Ms, lm), a0, a1, nd, sl, kind, &key, &len);
+                            else if (Dm == 3) slip_commit_mul<3>(wr_load<3>(Ms, lm), a0, a1, nd, sl, kind, &key, &len);
+                            else slip_commit_mul<4>(wr_load<4>(Ms, lm), a0, a1, nd, sl, kind, &key, &len);
+                            if (kind == 1) key = ~key;
+                            pbits = (int)(key >> 40); lp_ = len;
+                        }
+                        slip_wave_sync_lds();
+                        e_pivrow = (int) rows[cands[6 * bc]]; e_pivpos = (int) ck_pos[bc];
+                        pneg = (int)((ax >> 14) & 1u) ^ (M.len < 0);
+                        plimbs = (uint64_t)((lp_ + 1) >> 1);
+                        poff = lm > 2 ? Lnl_ + (int64_t)(ax & 0x3FFu) * slot : Lnl_ + (int64_t) nA * slot;
+                        lalloc = (uint64_t) nA * (uint64_t) slot + (lm > 2 ? 0ull : plimbs);
+                        if (lane == 0) ld_col[j & (SLIP_CB_RING - 1)] = 0xFFFFFFFFu;     /* its L values are long: not in the engine's ring */
+                    }
+                    SLIP_CT(15);
+                } else if (!reject && kindp == 1) {
+                    /* ---- kind 1: the chain engine ---- */
+                    const int nfull = (int) cb[22];
+                    const uint32_t *prow = cb + 128, *pvlo = prow + SLIP_PKG_FULLMAX, *pvhi = pvlo + SLIP_PKG_FULLMAX, *pmeta = pvhi + SLIP_PKG_FULLMAX;
+                    const int pr0 = sv[C_PR0];
+                    uint32_t lw = (uint32_t) sv[C_LW];
+                    SlipSmallPiv Mp = pring_get(j - 1);
+                    if (j - 1 < pr0 || !Mp.small) reject = 2;
+                    int nst = nfull;
+                    uint32_t lsrc[4] = {BIG, BIG, BIG, BIG};
+                    if (!reject) {
+                        /* E1: the state arrays and the row -> place table */
+                        for (int w = lane; w < 512; w += SLIP_WAVE) est_hash[w] = 0u;
+                        for (int q = 0; q < 2; q++) {
+                            const int t = lane + 64 * q;
+                            if (t < nfull) { est_row[t] = prow[t]; est_vlo[t] = pvlo[t]; est_vhi[t] = pvhi[t]; est_meta[t] = pmeta[t] & 0xBFFFFFFFu; }
+                        }
+                        slip_wave_sync_lds();
+                        for (int q = 0; q < 2; q++) { const int t = lane + 64 * q; if (t < nfull) est_insert(prow[t], t); }
+                        slip_wave_sync_lds();
+                        /* E2: the rows that have become pivotal since the export are the sources still to be applied */
+                        for (int q = 0; q < 4; q++) {
+                            const int t = lane + 64 * q;
+                            if (t < nst) { const uint32_t p = (uint32_t) pinvm[est_row[t]]; if ((int) p < j) lsrc[q] = p; }
                         }
                     }
-                    /* rho[j] for the next column: LDS to LDS */
-                    if (lp_ <= wcap) for (int c = lane; c < ((lp_ + 1) & ~1); c += SLIP_WAVE) Ms[c] = src[c];
+                    uint32_t ulate = 0;
+                    SLIP_CT(17);
+                    /* E3: the sources in ascending pivot position (slip_REF_triangular_solve.c:124-241) */
+                    while (!reject) {
+                        uint32_t mloc = lsrc[0] < lsrc[1] ? lsrc[0] : lsrc[1];
+                        { const uint32_t m2 = lsrc[2] < lsrc[3] ? lsrc[2] : lsrc[3]; if (m2 < mloc) mloc = m2; }
+                        const uint32_t cu = slip_wave_min_u32(mloc);
+                        if (cu == BIG) break;
+                        const int c = (int) cu;
+                        int oq = -1;
+                        for (int q = 0; q < 4; q++) if (lsrc[q] == cu) oq = q;
+                        const uint64_t ob = slip_ballot(oq >= 0);
+                        const int ol = slip_ctz64(ob);
+                        const int jt = ol + 64 * (int) slip_readlane((uint32_t)(oq < 0 ? 0 : oq), ol);
+                        if (oq >= 0) lsrc[oq] = BIG;
+                        const int cs = c & (SLIP_CB_RING - 1);
+                        if (c - 1 < pr0) { reject = 1; break; }
+                        if (ld_col[cs] != (uint32_t) c || (int32_t) ld_cnt[cs] < 0 || (uint32_t)(lw - ld_start[cs]) > (uint32_t) SLIP_LRING) {
+                            /* L(:,c) is not in the ring (its worker committed it, or it was pushed out): from memory if its worker has
+                             * published it (stage 2, Lready[c]) -- otherwise the package goes back and its worker waits for that */
+                            int rdy = 0;
+                            if (lane == 0) rdy = slip_agent_load_i32(&P.Lready[c]);
+                            rdy = (int) slip_bcast0_u32((uint32_t) rdy);
+                            if (!rdy) { reject = 1; break; }
+                            const int64_t m0 = slip_ld_i64(&P.Lp[c]), m1 = slip_ld_i64(&P.Lp[c + 1]);
+                            if (m1 - m0 > (int64_t) SLIP_ENG_ROWS || m1 < m0) { reject = 2; break; }
+                            const int cnt = (int)(m1 - m0);
+                            int bad = 0;
+                            for (int e0 = 0; e0 < cnt; e0 += SLIP_WAVE) {
+                                const int e = e0 + lane;
+                                if (e < cnt) {
+                                    const int ri = slip_ld_i32(&P.Li[m0 + e]);
+                                    const SlipEnt le = slip_ld_ent(&P.Le[m0 + e]);
+                                    uint64_t v = 0;
+                                    if (slip_abs(le.len) > 2) bad = 1;
+                                    else if (le.len != 0) v = slip_limb0_s((const dig_t *)(P.Llimbs + le.off));
+                                    const uint32_t at = 3u * ((lw + (uint32_t) e) % (uint32_t) SLIP_LRING);
+                                    lring[at] = (uint32_t) ri | (le.len < 0 ? 0x80000000u : 0u); lring[at + 1] = (uint32_t) v; lring[at + 2] = (uint32_t)(v >> 32);
+                                }
+                            }
+                            if (slip_ballot(bad)) { reject = 2; break; }
+                            if (lane == 0) { ld_start[cs] = lw; ld_cnt[cs] = (uint32_t) cnt; ld_col[cs] = (uint32_t) c; }
+                            lw += (uint32_t) cnt;
+                            slip_wave_sync_lds();
+                        }
+                        const SlipSmallPiv R = pring_get(c), Dv = pring_get(c - 1);
+                        if (!R.small || !Dv.small) { reject = 2; break; }
+                        const uint32_t jrow = est_row[jt];
+                        uint64_t xj = (uint64_t) est_vlo[jt] | ((uint64_t) est_vhi[jt] << 32);
+                        const uint32_t mj = est_meta[jt];
+                        int sj = xj ? ((mj >> 31) ? -1 : 1) : 0;
+                        const int hj = (int)(mj & 0x3FFFFFFFu) - 1;
+                        /* bring x[j] to its final value: history update to level c-1 (:139-149) */
+                        if (sj != 0 && hj < c - 1) {
+                            slip_u128 y = (slip_u128) xj * Dv.lo; sj *= Dv.sgn;
+                            if (hj >= 0) {
+                                const SlipSmallPiv H = pring_get(hj);
+                                if (hj < pr0 || !H.small) { reject = 2; break; }
+                                y = slip_divexact128(y, H.lo, H.ctz, H.inv); sj *= H.sgn;
+                            }
+                            if ((uint64_t)(y >> 64)) { reject = 2; break; }
+                            xj = (uint64_t) y;
+                        }
+                        slip_wave_sync_lds();                        /* every lane has read the row before one lane rewrites it */
+                        if (lane == 0) { est_vlo[jt] = (uint32_t) xj; est_vhi[jt] = (uint32_t)(xj >> 32); est_meta[jt] = (sj < 0 ? 0x80000000u : 0u) | 0x40000000u | (uint32_t)(hj + 1); }
+                        slip_wave_sync_lds();
+                        nlate++; ulate += xj != 0;
+                        const int src_nz = sj != 0, bxj = slip_bits64(xj);
+                        if (src_nz) { ec_src++; ec_read += 16; }
+                        const int dcnt = (int) ld_cnt[cs]; const uint32_t ds = ld_start[cs];
+                        for (int e0 = 0; e0 < dcnt && !reject; e0 += SLIP_WAVE) {
+                            const int e = e0 + lane, has = e < dcnt;
+                            uint32_t w0 = 0, lvl = 0, lvh = 0;
+                            if (has) { const uint32_t at = 3u * ((ds + (uint32_t) e) % (uint32_t) SLIP_LRING); w0 = lring[at]; lvl = lring[at + 1]; lvh = lring[at + 2]; }
+                            const uint32_t ri = w0 & 0x7FFFFFFFu;
+                            const uint64_t lv = (uint64_t) lvl | ((uint64_t) lvh << 32);
+                            int idx = has ? est_lookup(ri) : 0;
+                            const int fresh = has && idx < 0;
+                            const uint64_t fm = slip_ballot(fresh);
+                            const int nf = slip_popc64(fm);
+                            if (nst + nf > SLIP_ENG_ROWS) { reject = 2; break; }
+                            if (fresh) {
+                                /* structural discovery (what the reference's DFS does): a row the column did not hold yet */
+                                idx = nst + slip_popc64(fm & ((1ull << lane) - 1ull));
+                                est_row[idx] = ri; est_vlo[idx] = 0u; est_vhi[idx] = 0u; est_meta[idx] = 0u;
+                                est_insert(ri, idx);
+                            }
+                            const int nst_old = nst; nst += nf;
+                            int ovf = 0;
+                            const int upd = has && src_nz && ri != jrow && lv != 0;
+                            if (src_nz) {
+                                const uint64_t hm = slip_ballot(has), nzm = slip_ballot(has && lv != 0);
+                                ec_str += (unsigned long long) slip_popc64(hm); ec_read += 4ull * slip_popc64(hm) + 8ull * slip_popc64(nzm);
+                            }
+                            int had_x = 0;
+                            if (upd) {
+                                /* one IPGE update (:175-237) in 128-bit arithmetic */
+                                const uint64_t xi = (uint64_t) est_vlo[idx] | ((uint64_t) est_vhi[idx] << 32);
+                                const uint32_t mi = est_meta[idx];
+                                const int si = xi ? ((mi >> 31) ? -1 : 1) : 0, hi_ = (int)(mi & 0x3FFFFFFFu) - 1;
+                                const int lx = si != 0, hist = lx && hi_ < c - 1, hdiv = hist && hi_ > -1;
+                                had_x = lx;
+                                SlipSmallPiv H; H.lo = 1; H.inv = 1; H.ctz = 0; H.sgn = 1; H.small = 1; H.bits = 1;
+                                if (hdiv) { H = pring_get(hi_); if (hi_ < pr0 || !H.small) ovf = 1; }
+                                const int bxi = slip_bits64(xi);
+                                const int bxp = !lx ? 0 : (!hist ? bxi : (hdiv ? bxi + Dv.bits - H.bits + 1 : bxi + Dv.bits));
+                                const int b1b = lx ? bxp + R.bits : 0, b2b = slip_bits64(lv) + bxj;
+                                if ((b1b > b2b ? b1b : b2b) + 1 > 126) ovf = 1;
+                                if (!ovf) {
+                                    slip_u128 y = 0; int s1 = si * R.sgn;
+                                    if (lx) {
+                                        y = (slip_u128) xi;
+                                        if (hist) { y *= Dv.lo; s1 *= Dv.sgn; }
+                                        if (hdiv) { y = slip_divexact128(y, H.lo, H.ctz, H.inv); s1 *= H.sgn; }
+                                        y *= R.lo;
+                                    }
+                                    const slip_u128 p2 = (slip_u128) lv * xj;
+                                    const int s2 = ((w0 >> 31) ? -1 : 1) * sj;
+                                    slip_u128 mag; int sT;
+                                    if (!lx) { mag = p2; sT = -s2; }
+                                    else if (s1 == s2) { if (y >= p2) { mag = y - p2; sT = s1; } else { mag = p2 - y; sT = -s1; } }
+                                    else { mag = y + p2; sT = s1; }
+                                    mag = slip_divexact128(mag, Dv.lo, Dv.ctz, Dv.inv); sT *= Dv.sgn;      /* c >= 1 here */
+                                    if ((uint64_t)(mag >> 64)) ovf = 1;
+                                    else {
+                                        const uint64_t nv = (uint64_t) mag;
+                                        est_vlo[idx] = (uint32_t) nv; est_vhi[idx] = (uint32_t)(nv >> 32);
+                                        est_meta[idx] = (nv && sT < 0 ? 0x80000000u : 0u) | (uint32_t)(c + 1);
+                                    }
+                                }
+                            }
+                            {
+                                const uint64_t um = slip_ballot(upd), xm = slip_ballot(upd && had_x);
+                                ec_upd += (unsigned long long) slip_popc64(um); ec_mac += (unsigned long long)(slip_popc64(um) + slip_popc64(xm));
+                            }
+                            if (slip_ballot(ovf)) { reject = 2; break; }
+                            slip_wave_sync_lds();
+                            for (int q = 0; q < 4; q++) {                       /* a filled-in row may itself have become pivotal meanwhile: a later source */
+                                const int t = lane + 64 * q;
+                                if (t >= nst_old && t < nst) { const uint32_t p = (uint32_t) pinvm[est_row[t]]; lsrc[q] = (int) p < j ? p : BIG; }
+                            }
+                        }
+                    }
+                    SLIP_CT(18);
+                    /* E4: the non-pivotal rows to level j-1 (:248-257), the pivot search among them */
+                    int pt = -1;
+                    if (!reject) {
+                        uint64_t fin[4]; int fneg[4], isL[4]; int ovf = 0;
+                        for (int q = 0; q < 4; q++) {
+                            const int t = lane + 64 * q;
+                            fin[q] = 0; fneg[q] = 0; isL[q] = 0;
+                            if (t < nst) {
+                                const uint32_t m = est_meta[t];
+                                if (!((m >> 30) & 1u)) {
+                                    isL[q] = 1;
+                                    uint64_t x = (uint64_t) est_vlo[t] | ((uint64_t) est_vhi[t] << 32);
+                                    if (x) {
+                                        int s_ = (m >> 31) ? -1 : 1; const int h = (int)(m & 0x3FFFFFFFu) - 1;
+                                        if (h < j - 1) {
+                                            slip_u128 y = (slip_u128) x * Mp.lo; s_ *= Mp.sgn;
+                                            if (h >= 0) {
+                                                const SlipSmallPiv H = pring_get(h);
+                                                if (h < pr0 || !H.small) ovf = 1; else { y = slip_divexact128(y, H.lo, H.ctz, H.inv); s_ *= H.sgn; }
+                                            }
+                                            if ((uint64_t)(y >> 64)) ovf = 1;
+                                            x = (uint64_t) y;
+                                        }
+                                        fin[q] = x; fneg[q] = s_ < 0;
+                                    }
+                                }
+                            }
+                        }
+                        if (slip_ballot(ovf)) reject = 2;
+                        if (!reject) {
+                            uint64_t Lex = 0; int nLl = 0;
+                            uint64_t kmin = ~0ull;
+                            for (int q = 0; q < 4; q++) {
+                                const int t = lane + 64 * q;
+                                if (isL[q]) { est_vlo[t] = (uint32_t) fin[q]; est_vhi[t] = (uint32_t)(fin[q] >> 32); est_meta[t] = (fneg[q] ? 0x80000000u : 0u) | (uint32_t) j; }
+                                nLl += slip_popc64(slip_ballot(isL[q])); Lex += (uint64_t) slip_popc64(slip_ballot(isL[q] && fin[q] != 0));
+                                const uint64_t key = (isL[q] && fin[q]) ? (kind == 0 ? fin[q] : ~fin[q]) : ~0ull;
+                                if (key < kmin) kmin = key;
+                            }
+                            const uint32_t mh = slip_wave_min_u32((uint32_t)(kmin >> 32));
+                            const uint32_t ml = slip_wave_min_u32((uint32_t)(kmin >> 32) == mh ? (uint32_t) kmin : 0xFFFFFFFFu);
+                            const uint64_t mk = ((uint64_t) mh << 32) | ml;
+                            if (mk == ~0ull) reject = 2;            /* no nonzero non-pivotal row: the worker reports the singular column */
+                            else {
+                                /* equal values: the earlier pattern position wins (slip_get_smallest_pivot.c:79) */
+                                uint32_t bpos = BIG; int bq = -1;
+                                for (int q = 0; q < 4; q++) {
+                                    const int t = lane + 64 * q;
+                                    const uint64_t key = (isL[q] && fin[q]) ? (kind == 0 ? fin[q] : ~fin[q]) : ~0ull;
+                                    if (key == mk) { const uint32_t p = (uint32_t) pinvm[est_row[t]]; if (p < bpos) { bpos = p; bq = q; } }
+                                }
+                                const uint32_t bp = slip_wave_min_u32(bpos);
+                                const uint64_t bmk = slip_ballot(bq >= 0 && bpos == bp);
+                                const int bl = slip_ctz64(bmk);
+                                pt = bl + 64 * (int) slip_readlane((uint32_t)(bq < 0 ? 0 : bq), bl);
+                                /* the diagonal preference on the final values (slip_get_pivot.c:68-76, 89-118, 126-146) */
+                                if (diagpref && est_row[pt] != (uint32_t) col) {
+                                    int dt = -1;
+                                    if (lane == 0) dt = est_lookup((uint32_t) col);
+                                    dt = (int) slip_bcast0_u32((uint32_t) dt);
+                                    if (dt >= 0 && !((est_meta[dt] >> 30) & 1u)) {
+                                        const uint64_t dv = (uint64_t) est_vlo[dt] | ((uint64_t) est_vhi[dt] << 32);
+                                        const uint64_t bv = (uint64_t) est_vlo[pt] | ((uint64_t) est_vhi[pt] << 32);
+                                        if (dv != 0) {
+                                            if (scheme == 1 || P.tol_mode == 0) pt = dt;
+                                            else {
+                                                const int tk = slip_tol_small(P.tol_m, P.tol_e, scheme == 3 ? bv : dv, scheme == 3 ? dv : bv);
+                                                if (tk < 0) reject = 2; else if (tk) pt = dt;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                            /* E5: the sums of stage 1 */
+                            if (!reject) {
+                                nUc_all = (int) cb[3] + nlate; U_l = (uint64_t) cb[4] + (uint64_t) ulate; nLc = nLl;
+                                Lb_total = Lex; plimbs = 1; lalloc = 1; poff = Lnl_;
+                                if (Lnz_ + nLc > P.Lcap_nz || Lnl_ + (int64_t) Lb_total > P.Lcap_nl) reject = 2;
+                                if (Unz_ + nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t)(U_l + plimbs) > P.Ucap_nl) reject = 2;
+                            }
+                            if (!reject) {
+                                const uint64_t pv = (uint64_t) est_vlo[pt] | ((uint64_t) est_vhi[pt] << 32);
+                                e_pivrow = (int) est_row[pt]; e_pivpos = (int) pinvm[est_row[pt]];
+                                pneg = (int)(est_meta[pt] >> 31); pbits = slip_bits64(pv); lp_ = (pbits + 31) >> 5;
+                                if (lane == 0) { sl[0] = (uint32_t) pv; sl[1] = (uint32_t)(pv >> 32); }
+                                nfin = nst;
+                                /* the rows go back to the worker: values final, positions as the reference has them at column j (the
+                                 * stores are issued here and drained with the batch) */
+                                uint32_t *hb = mbx + SLIP_MBOX_HDR;
+                                for (int q = 0; q < 4; q++) {
+                                    const int t = lane + 64 * q;
+                                    if (t < nst) {
+                                        const uint32_t m = est_meta[t];
+                                        slip_st_u32(hb + t, est_row[t]); slip_st_u32(hb + SLIP_ENG_ROWS + t, est_vlo[t]); slip_st_u32(hb + 2 * SLIP_ENG_ROWS + t, est_vhi[t]);
+                                        slip_st_u32(hb + 3 * SLIP_ENG_ROWS + t, (m & 0xC0000000u) | (uint32_t) pinvm[est_row[t]]);
+                                    }
+                                }
+                                /* L(:,j) as the later columns of the run will read it: into the ring */
+                                {
+                                    uint32_t at0 = lw;
+                                    for (int q = 0; q < 4; q++) {
+                                        const int t = lane + 64 * q;
+                                        const uint64_t lm_ = slip_ballot(isL[q]);
+                                        if (isL[q]) {
+                                            const uint32_t at = 3u * ((at0 + (uint32_t) slip_popc64(lm_ & ((1ull << lane) - 1ull))) % (uint32_t) SLIP_LRING);
+                                            lring[at] = est_row[t] | (fneg[q] ? 0x80000000u : 0u); lring[at + 1] = (uint32_t) fin[q]; lring[at + 2] = (uint32_t)(fin[q] >> 32);
+                                        }
+                                        at0 += (uint32_t) slip_popc64(lm_);
+                                    }
+                                    if (lane == 0) { ld_start[j & (SLIP_CB_RING - 1)] = lw; ld_cnt[j & (SLIP_CB_RING - 1)] = (uint32_t) nLc; ld_col[j & (SLIP_CB_RING - 1)] = (uint32_t) j; }
+                                    lw += (uint32_t) nLc;
+                                }
+                            }
+                        }
+                    }
+                    SLIP_CT(19);
+                    if (lane == 0) sv[C_LW] = (int32_t) lw;                                                   /* (columns fetched from memory stay in the ring also when this package goes back) */
+                    if (reject && lane == 0) slip_st_u32(mbx + SLIP_PKG_OUT + 1, (uint32_t) reject);      /* why it goes back (1: try again later) */
                 }
-                if (lane == 0) sv[C_ST] = est;
+                slip_wave_sync_lds();
+#if defined(SLIP_EMULATE) && defined(SLIP_EMU_TRACE)
+                if (lane == 0) fprintf(stderr, "committer: col %d kind %d reject %d pre %d (stamp0 %d nfull %d nrows %d nlate %d pr0 %d ring0 %d)\n", j, kindp, reject, (int) cb[18], stamp0, (int) cb[22], nrows, nlate, sv[C_PR0], sv[C_RING0]);
+#endif
+                if (reject) { rej = j; break; }
+                /* ---- the column is committed: what the next one needs, in LDS; what the publish step needs, in its record ---- */
+                {
+                    SlipPiv pr; pr.off = poff; pr.len = pneg ? -lp_ : lp_; pr.bits = pbits; pr.invlen = 0; pr.pad = 0;
+                    pr.lo = (uint64_t) sl[0] | ((uint64_t) sl[1] << 32);
+                    int z = 0;
+                    if (lp_ <= 2) z = slip_ctz64(pr.lo);
+                    pr.ctz = z; pr.inv64 = lp_ <= 2 ? slip_inv64(pr.lo >> z) : 0;
+                    const int64_t nUnz = Unz_ + nUc_all + 1, nLnz = Lnz_ + nLc;
+                    const int64_t nUnl = Unl_ + (int64_t)(U_l + plimbs), nLnl = Lnl_ + (int64_t) Lb_total;
+                    /* rho[j] for the next column: LDS to LDS */
+                    if (lp_ <= SLIP_CB_SLOTW - 6) for (int c = lane; c < ((lp_ + 1) & ~1); c += SLIP_WAVE) Ms[c] = sl[c];
+                    if (lane == 0) {
+                        *Mrec = pr;                                      /* (ctz of a long pivot is found while its digits are published; nobody reads it here) */
+                        pring_put(j, pr);
+                        sv64[SV_LNZ / 2] = nLnz; sv64[SV_LNL / 2] = nLnl; sv64[SV_UNZ / 2] = nUnz; sv64[SV_UNL / 2] = nUnl;
+                        ring_row[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivrow; ring_disp[j & (SLIP_CB_RING - 1)] = (uint32_t) intermed2;
+                        ring_opos[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivpos;
+                        if (j + 1 - sv[C_RING0] > SLIP_CB_RING) sv[C_RING0] = j + 1 - SLIP_CB_RING;
+                        if (j + 1 - sv[C_PR0] > SLIP_CB_RING) sv[C_PR0] = j + 1 - SLIP_CB_RING;
+#if defined(SLIP_EMULATE) && defined(SLIP_EMU_TRACE)
+                        fprintf(stderr, "commit col %d kind %d: pivot row %d from pos %d, row %d (loaded %d) goes there; mirror says row at... pinvm[piv] %d pinvm[im2] %d\n", j, kindp, e_pivrow, e_pivpos, intermed2, (int) cb[17], mirror ? (int) pinvm[e_pivrow] : -1, mirror ? (int) pinvm[intermed2] : -1);
+#endif
+                        if (mirror) { pinvm[e_pivrow] = (uint16_t) j; pinvm[intermed2] = (uint16_t) e_pivpos; }
+                        sv[C_LASTPR] = e_pivrow;
+                        pb[0] = (uint32_t) e_pivrow; pb[1] = (uint32_t) e_pivpos; pb[2] = (uint32_t) intermed2; pb[3] = (uint32_t)(pneg ? -lp_ : lp_); pb[4] = (uint32_t) pbits;
+                        pb[5] = (uint32_t) lp_; pb[6] = (uint32_t) nfin; pb[7] = (uint32_t) nlate;
+                        pb[8] = (uint32_t) poff; pb[9] = (uint32_t)((uint64_t) poff >> 32); pb[10] = (uint32_t) lalloc; pb[11] = (uint32_t)(lalloc >> 32);
+                        pb[12] = (uint32_t) nUnz; pb[13] = (uint32_t)((uint64_t) nUnz >> 32); pb[14] = (uint32_t) nLnz; pb[15] = (uint32_t)((uint64_t) nLnz >> 32);
+                        pb[16] = (uint32_t) nUnl; pb[17] = (uint32_t)((uint64_t) nUnl >> 32); pb[18] = (uint32_t) nLnl; pb[19] = (uint32_t)((uint64_t) nLnl >> 32);
+                        pb[20] = cb[20]; pb[21] = (uint32_t) kindp;
+                        if (kindp == 1) {
+                            eacc[0] += ec_src; eacc[1] += ec_read; eacc[2] += ec_str; eacc[3] += ec_upd; eacc[4] += ec_mac;
+                            eacc[5] += 1ull; eacc[6] += (unsigned long long) nlate;
+                        }
+                    }
+                    /* the permutation swap (slip_get_pivot.c:164-176) is stored HERE, by this one wave, column after column:
+                     * successive columns of a batch write the same words (a row displaced to position p, the next pivot taken from
+                     * p), and only stores of one wave to one address keep their order */
+                    {
+                        uint32_t *a4 = (uint32_t *) 0; uint32_t v4 = 0;
+                        switch (lane) {
+                            case 0: a4 = (uint32_t *) &P.row_perm[j]; v4 = (uint32_t) e_pivrow; break;
+                            case 1: a4 = (uint32_t *) &P.row_perm[e_pivpos]; v4 = (uint32_t) intermed2; break;
+                            case 2: a4 = (uint32_t *) &P.pinv[e_pivrow]; v4 = (uint32_t) j; break;
+                            case 3: a4 = (uint32_t *) &P.pinv[intermed2]; v4 = (uint32_t) e_pivpos; break;
+                            default: break;
+                        }
+                        /* (lanes of ONE store instruction to one address have no order: when the pivot already sits at position j,
+                         * lanes 0/1 and 2/3 write identical values) */
+                        if (a4) slip_st_u32(a4, v4);
+                    }
+                    slip_wave_sync_lds();
+                }
+                SLIP_CT(16);
+                nbc = i + 1;
             }
-            SLIP_CT(14);
-            slip_block_sync();
-            SLIP_CT(15);
-            if (sv[C_ST]) { rej = j; break; }
-            nbc = i + 1;
+            if (lane == 0) { sv[C_NBC] = nbc; sv[C_ST] = rej; }
         }
+        slip_block_sync();
         SLIP_CT(3);                                  /* 3: the serial part */
-        /* (d) everything issued above has left; then the verdicts and the frontier */
+        const int nbc = sv[C_NBC], rej = sv[C_ST];
+        /* (d) stage 1 of the committed columns, side by side: the pivot's digits written through, its record, the swap and its
+         *     log, the column pointers, the outcome for the worker */
+        for (int i = wave; i < nbc; i += nw) {
+            const int j = kc + i;
+            const uint32_t *pb = pub + i * SLIP_PUBW;
+            const dig_t *src = stage + i * SLIP_CB_SLOTW;
+            uint32_t *mbx = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) pb[20] * SLIP_MBOX_WORDS;
+            const int e_pivrow = (int) pb[0], e_pivpos = (int) pb[1], intermed2 = (int) pb[2], lp_ = (int) pb[5];
+            const int64_t poff = (int64_t)((uint64_t) pb[8] | ((uint64_t) pb[9] << 32));
+            const int z = slip_publish_digits((dig_t *)(P.Llimbs + poff), src, 0, lp_);
+            SlipPiv pr; pr.off = poff; pr.len = (int32_t) pb[3]; pr.bits = (int32_t) pb[4]; pr.ctz = z; pr.invlen = 0;
+            pr.lo = *(const uint64_t *) src; pr.inv64 = 0; pr.pad = 0;
+            if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
+            /* every lane computes the same values; lane q issues store q: two store instructions instead of twenty-odd */
+            {
+                uint64_t *a8 = (uint64_t *) 0; uint64_t v8 = 0;
+                uint64_t *pw = (uint64_t *) &P.piv[j];
+                switch (lane) {
+                    case 0: a8 = pw; v8 = (uint64_t) pr.off; break;
+                    case 1: a8 = pw + 1; v8 = (uint64_t)(uint32_t) pr.len | ((uint64_t)(uint32_t) pr.bits << 32); break;
+                    case 2: a8 = pw + 2; v8 = pr.lo; break;
+                    case 3: a8 = pw + 3; v8 = (uint64_t)(uint32_t) pr.ctz; break;
+                    case 4: a8 = pw + 4; v8 = pr.inv64; break;
+                    case 5: a8 = (uint64_t *) &P.Up[j + 1]; v8 = (uint64_t) pb[12] | ((uint64_t) pb[13] << 32); break;
+                    case 6: a8 = (uint64_t *) &P.Lp[j + 1]; v8 = (uint64_t) pb[14] | ((uint64_t) pb[15] << 32); break;
+                    case 7: a8 = (uint64_t *) &P.Uo[j + 1]; v8 = (uint64_t) pb[16] | ((uint64_t) pb[17] << 32); break;
+                    case 8: a8 = (uint64_t *) &P.Lo[j + 1]; v8 = (uint64_t) pb[18] | ((uint64_t) pb[19] << 32); break;
+                    case 9: a8 = (uint64_t *)(mbx + SLIP_PKG_OUT + 6); v8 = (uint64_t) poff; break;
+                    case 10: a8 = (uint64_t *)(mbx + SLIP_PKG_OUT + 8); v8 = (uint64_t) pb[10] | ((uint64_t) pb[11] << 32); break;
+                    default: break;
+                }
+                if (a8) slip_st_u64(a8, v8);
+                uint32_t *a4 = (uint32_t *) 0; uint32_t v4 = 0;
+                switch (lane) {
+                    case 4: a4 = (uint32_t *) &P.sw_row[j]; v4 = (uint32_t) intermed2; break;
+                    case 5: a4 = (uint32_t *) &P.sw_pos[j]; v4 = (uint32_t) e_pivpos; break;
+                    case 6: a4 = mbx + SLIP_PKG_OUT + 1; v4 = (uint32_t) e_pivrow; break;
+                    case 7: a4 = mbx + SLIP_PKG_OUT + 2; v4 = (uint32_t) e_pivpos; break;
+                    case 8: a4 = mbx + SLIP_PKG_OUT + 3; v4 = pb[3]; break;
+                    case 9: a4 = mbx + SLIP_PKG_OUT + 4; v4 = pb[4]; break;
+                    case 10: a4 = mbx + SLIP_PKG_OUT + 5; v4 = pb[6]; break;
+                    case 11: a4 = mbx + SLIP_PKG_OUT + 10; v4 = pb[7]; break;
+                    default: break;
+                }
+                if (a4) slip_st_u32(a4, v4);
+            }
+        }
+        slip_vm_drain();                             /* every wave's stores of this batch have left */
+        slip_block_sync();
+        SLIP_CT(4);                                  /* 4: publish + drain */
+        /* (e) the verdicts and the frontier */
         if (wave == 0) {
             slip_vm_drain();
-            if (lane < nbc) slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t)(base + lane * SLIP_CBW)[20] * SLIP_MBOX_WORDS + SLIP_PKG_OUT, (hver[lane] << 24) | (uint32_t)(kc + lane + 1));
+            if (lane < nbc) slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t)(pub + lane * SLIP_PUBW)[20] * SLIP_MBOX_WORDS + SLIP_PKG_OUT, (hver[lane] << 24) | (uint32_t)(kc + lane + 1));
 #ifdef SLIP_PROFILE_PHASES
             if (lane < nbc) P.dbg[18 * (int64_t) P.n + 6 * (int64_t)(kc + lane) + 2] = (int32_t) slip_realtime();  /* time line 2: committed by the committer */
 #endif
             if (lane == 0) {
                 if (rej >= 0) {
                     const uint32_t rv = hver[rej - kc];
-                    const uint32_t rw = (base + (rej - kc) * SLIP_CBW)[20];
+                    const uint32_t rw = (cbuf + (rej - kc) * SLIP_CBW)[20];
                     if (rw < (uint32_t) P.nworkers) slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) rw * SLIP_MBOX_WORDS + SLIP_PKG_OUT, (uint32_t)(-(int32_t)((rv << 24) | (uint32_t)(rej + 1))));
                     sv[C_REJ] = rej; sv[C_REJV] = (int32_t) rv;
                 }
@@ -498,11 +971,20 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 }
             }
         }
-        SLIP_CT(4);                                  /* 4: the drain */
+        SLIP_CT(5);                                  /* 5: verdicts + frontier */
 #ifdef SLIP_PROFILE_COMMIT
-        if (tid == 0) { tacc_[5] += 1; tacc_[6] += (unsigned long long) nbc; tacc_[7] += rej >= 0; tacc_[8] += (unsigned long long) nb; }
+        if (tid == 0) { tacc_[6] += 1; tacc_[7] += (unsigned long long) nbc; tacc_[8] += rej >= 0; tacc_[9] += (unsigned long long) nb; }
 #endif
         slip_block_sync();
+    }
+    /* the engine's share of the algorithmic counters: the sources it applied in place of the workers */
+    if (tid == 0) {
+        if (eacc[0]) slip_agent_add_u64(&st->c_src, eacc[0]);
+        if (eacc[1]) slip_agent_add_u64(&st->c_read, eacc[1]);
+        if (eacc[2]) slip_agent_add_u64(&st->c_streamed, eacc[2]);
+        if (eacc[3]) slip_agent_add_u64(&st->c_upd, eacc[3]);
+        if (eacc[4]) slip_agent_add_u64(&st->c_macs, eacc[4]);
+        if (eacc[5] || eacc[6]) slip_agent_add_u64(&st->c_eng, eacc[5] | (eacc[6] << 32));
     }
 #ifdef SLIP_PROFILE_COMMIT
     if (tid == 0) for (int q = 0; q < 24; q++) st->prof[q] = tacc_[q];      /* (the workers' own slots are added on top: read the committer's with workers that do not stamp) */

@@ -182,8 +182,36 @@ slip_factor_kernel(SlipParams P, SlipState *st)
     __shared__ SlipParams sP;
     if (threadIdx.x == 0) slip_worker_params(&sP, P, (int) blockIdx.x);
     __syncthreads();
-    if (sP.committer && blockIdx.x == 0) slip_committer<FAST>(sP, st, slip_lds);
-    else slip_factor_worker<FAST>(sP, st, slip_lds);
+    /* where this workgroup runs: HW_ID (cu_id bits 11:8, sh_id 12, se_id 15:13) and the XCC id.  The instruction cache is
+     * shared by neighbouring CUs: a column worker next to the committer evicts the committer's short loop all the time
+     * (the worker's code is far larger than the cache), so the workers on the committer's neighbours stand aside
+     * (P.quiet_neighbours; placement is read, never assumed: a worker that does not see the committer just works) */
+    const uint32_t hwid = (uint32_t) __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = (uint32_t) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
+    const uint32_t where = ((hwid >> 8) & 0xFFu) | (xcc << 8);          /* cu | sh | se | xcc */
+    if (threadIdx.x == 0 && blockIdx.x < 2048) P.dbg[24 * (int64_t) P.n + 2048 + blockIdx.x] = (int32_t)(where | 0x10000u);
+    if (sP.committer && blockIdx.x == 0) {
+        if (threadIdx.x == 0) slip_st_i32(&st->committer_where, (int32_t)(where | 0x10000u));
+        slip_committer<FAST>(sP, st, slip_lds);
+    } else {
+        int stand_aside = 0;
+        if (sP.committer && sP.quiet_neighbours) {
+            __shared__ int aside_;
+            if (threadIdx.x == 0) {
+                int cw = 0;
+                for (int spin = 0; spin < 4000 && !(cw = slip_ld_i32(&st->committer_where)); spin++) slip_sleep();
+                aside_ = 0;
+                if (cw) {
+                    const uint32_t c = (uint32_t) cw;
+                    const int same_array = ((c >> 4) & 0xFFu) == ((where >> 4) & 0xFFu);       /* sh, se, xcc */
+                    const int dcu = (int)(c & 0xFu) - (int)(where & 0xFu);
+                    aside_ = same_array && dcu >= -sP.quiet_neighbours && dcu <= sP.quiet_neighbours;
+                }
+            }
+            __syncthreads();
+            stand_aside = aside_;
+        }
+        if (!stand_aside) slip_factor_worker<FAST>(sP, st, slip_lds);
+    }
     slip_worker_exit(sP, st);
 }
 
@@ -260,6 +288,8 @@ struct slip_hip_factor {
     int32_t workers_asked; /* slip_hip_options.workers (0: as many as can be resident) */
     int32_t no_committer;  /* diagnostics: every column is committed by its own worker */
     int32_t no_farm;       /* diagnostics: long update queues are not opened to other workers */
+    int32_t no_engine;     /* diagnostics: no full packages (the committer's chain engine stays off) */
+    int32_t engine_ok;     /* the committer's LDS layout with the pinv mirror fits */
     int32_t last_status, window_end, launches;
     int32_t factors_only;  /* built from given factors (slip_hip_factor_from_factors): solve only, no A */
     double kernel_ms, solve_ms;
@@ -456,6 +486,10 @@ static void plan_launch(slip_hip_factor *f)
     f->waves = nw;
     f->lds_words = fixed + (f->scratch_in_lds ? (nw * 3 + 1) * P->wcap : 0);
     P->bitmap_in_lds = f->bitmap_in_lds; P->scratch_in_lds = f->scratch_in_lds;
+    /* block 0 of a factorisation launch may be the committer (ref_lu_pipe_commit.h): its rings, package copies and -- for
+     * matrices up to SLIP_MIRROR_MAX rows -- the chain engine's mirror of pinv live in the same dynamic LDS */
+    f->engine_ok = P->n <= SLIP_MIRROR_MAX && !f->no_engine;
+    { const int cw = slip_commit_lds_words(P->n, f->engine_ok); if (!f->factors_only && cw <= SLIP_LDS_MAX_WORDS && cw > f->lds_words) f->lds_words = cw; }
 }
 
 #ifdef SLIP_EMULATE
@@ -605,6 +639,8 @@ static void apply_options(slip_hip_factor *f, const slip_hip_options &opt)
     f->P.no_early = opt.reserved & 1;
     f->no_committer = (opt.reserved >> 1) & 1;
     f->no_farm = (opt.reserved >> 2) & 1;
+    f->no_engine = (opt.reserved >> 3) & 1;
+    f->P.quiet_neighbours = (opt.reserved >> 4) & 3;      /* experiment: workers within this many CUs of the committer stand aside */
 }
 
 static int make_ident(slip_hip_factor *f)
@@ -781,7 +817,7 @@ extern "C" int slip_emu_corrupt_entry(slip_hip_factor *f, int isU, long long t, 
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
     f->P.k0 = f->hs.F; f->P.t0 = f->hs.ticket;
-    f->hs.stop = INT64_MAX; f->hs.exited = 0; for (int q_ = 0; q_ < 8; q_++) f->hs.farm_hint[q_] = 0; f->hs.dbg_who = 0;
+    f->hs.stop = INT64_MAX; f->hs.exited = 0; for (int q_ = 0; q_ < 8; q_++) f->hs.farm_hint[q_] = 0; f->hs.dbg_who = 0; f->hs.committer_up = 0; f->hs.committer_where = 0;
     f->P.st = f->ds; f->P.in_factor = 1;
     { const int e = upload_state(f, stream); if (e) return e; }
     /* no more workers than columns left */
@@ -791,6 +827,8 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
     if (W > f->P.k_stop - f->hs.F + f->P.committer) W = f->P.k_stop - f->hs.F + f->P.committer;
     if (W < 1) W = 1;
     if (W < 2) f->P.committer = 0;
+    if (f->P.committer && slip_commit_lds_words(f->P.n, 0) > f->lds_words) f->P.committer = 0;      /* (cannot happen: plan_launch made room) */
+    f->P.engine = f->P.committer && f->engine_ok && slip_commit_lds_words(f->P.n, 1) <= f->lds_words;
     f->P.nworkers = W;
     if (f->P.committer) CK(hipMemsetAsync(f->P.pkg, 0, (size_t) W * (SLIP_PKG_WORDS + SLIP_MBOX_WORDS) * 4, stream));
     f->P.farm = W >= 2 && !f->no_farm && f->P.jobs != NULL;
@@ -1295,6 +1333,14 @@ extern "C" int slip_hip_factor_column_trace(const slip_hip_factor *f, int32_t *o
     return SLIP_HIP_OK;
 }
 
+/* diagnostic: raw words of the device debug area (placement of the workgroups of the last launch at 24 n + 2048: cu | sh | se | xcc) */
+extern "C" int slip_hip_factor_debug_words(const slip_hip_factor *f, int64_t offset, int32_t count, int32_t *out)
+{
+    if (!f || !out || offset < 0 || count <= 0 || offset + count > 24 * (int64_t) f->n + 4096) return SLIP_HIP_INCORRECT_INPUT;
+    CK(hipMemcpy(out, f->P.dbg + offset, (size_t) count * 4, hipMemcpyDeviceToHost));
+    return SLIP_HIP_OK;
+}
+
 extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)
 {
     if (!f || !o) return SLIP_HIP_INCORRECT_INPUT;
@@ -1308,6 +1354,8 @@ extern "C" int slip_hip_factor_info(const slip_hip_factor *f, slip_hip_info *o)
     o->limb_macs = (int64_t) h->c_macs; o->workers = f->nworkers; o->waves = f->waves; o->lds_bytes = f->lds_words * 4;
     o->short_commits = (int32_t)(uint32_t) h->c_short; o->committer_commits = (int32_t)(h->c_short >> 32);
     o->farm_jobs = (int32_t)(uint32_t) h->c_farm; o->farm_items = (int32_t)(h->c_farm >> 32);
+    o->engine_commits = (int32_t)(uint32_t) h->c_eng; o->engine_sources = (int32_t)(h->c_eng >> 32);
+    o->retractions = (int32_t)(uint32_t) h->c_retract; o->reexports = (int32_t)(h->c_retract >> 32); o->pad2 = 0;
     return SLIP_HIP_OK;
 }
 

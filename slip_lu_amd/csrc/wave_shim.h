@@ -64,6 +64,7 @@ static inline uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o 
 static inline int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v > o) *p = v; return o; }
 static inline int32_t  slip_atomic_min_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v < o) *p = v; return o; }
 static inline int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
+static inline uint32_t slip_atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { uint32_t o = *p; if (o == expect) *p = v; return o; }
 static inline unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline void slip_fence_block(void) {}
 static inline void slip_fence_device(void) {}
@@ -203,6 +204,7 @@ SLIP_DEV uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(
 SLIP_DEV int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { return atomicMax(p, v); }
 SLIP_DEV int32_t  slip_atomic_min_i32(int32_t *p, int32_t v) { return atomicMin(p, v); }
 SLIP_DEV int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { return atomicAdd(p, v); }
+SLIP_DEV uint32_t slip_atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { return atomicCAS(p, expect, v); }      /* returns the value found */
 SLIP_DEV unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 SLIP_DEV void slip_fence_block(void) { __threadfence_block(); }
 SLIP_DEV void slip_fence_device(void) { __threadfence(); }
