@@ -169,7 +169,7 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
        SV_PP = 36 /* SLIP_PP_WORDS words: what the pre-pass of the commit chain found (slip_prepass) */,
        SV_PPF = 50 /* pre-pass: non-pivotal rows of a column that can travel as a FULL package (every value one limb), or -1 */,
        SV_PKGK = 51 /* kind of the exported package: 0 candidates, 1 full */, SV_NOK1 = 52 /* 1: no (more) full packages for this column */,
-       SV_CUP = 53 /* the committer has been seen running */, SV_PPFL = 55 /* the frontier (threshold) the last pre-pass ran at */, SV_K1STAMP = 54 /* a full package is only exported beyond this frontier (the stamp of one that was sent back) */,
+       SV_CUP = 53 /* the committer has been seen running */, SV_PPFL = 55 /* the frontier (threshold) the last pre-pass ran at */, SV_NOENG = 56 /* the column at which this WORKER last saw a pivot of more than one limb (full packages are not tried for a while); survives the columns */, SV_K1STAMP = 54 /* a full package is only exported beyond this frontier (the stamp of one that was sent back) */,
        SV_PKGVER = 60 /* version of this worker's exported package (0: none yet) */, SV_PKGX = 61 /* 1: exported and still valid */,
        SV_PKGF = 62 /* the frontier the package's positions were read at */ };
 #define SLIP_PP_WORDS  14
@@ -435,10 +435,17 @@ SLIP_DEV int slip_bits128(slip_u128 v)
 }
 SLIP_DEV uint64_t slip_inv64(uint64_t d)            /* d odd */
 {
-    uint64_t x = d;
-    x *= 2 - d * x; x *= 2 - d * x; x *= 2 - d * x; x *= 2 - d * x; x *= 2 - d * x;
-    return x;
+    /* Newton on the low word first (32-bit multiplies are a quarter of the work of 64-bit ones): 3 -> 6 -> 12 -> 24 -> 48 bits */
+    const uint32_t d32 = (uint32_t) d;
+    uint32_t x = d32;                                /* d * d = 1 mod 8 */
+    x *= 2u - d32 * x; x *= 2u - d32 * x; x *= 2u - d32 * x; x *= 2u - d32 * x;
+    uint64_t X = x;
+    X *= 2 - d * X;                                  /* 32 -> 64 bits */
+    return X;
 }
+/* v / d for an exact division whose quotient is known to fit 64 bits (bits(v) - bits(d) + 1 <= 64): the low 64 bits of
+ * (v >> ctz) times the 64-bit inverse of d's odd part ARE the quotient */
+SLIP_DEV uint64_t slip_divexact_to64(slip_u128 v, int z, uint64_t inv64) { return (uint64_t)(v >> z) * inv64; }
 /* v / d exactly, v < 2^128, d a one-limb divisor with ctz z and 64-bit inverse of its odd part */
 SLIP_DEV slip_u128 slip_divexact128(slip_u128 v, uint64_t d, int z, uint64_t inv64)
 {

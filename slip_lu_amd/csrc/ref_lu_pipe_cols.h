@@ -47,8 +47,10 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, i
             const int64_t stop = slip_ld_i64(&st->stop);
             if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             /* the further from its turn, the longer between polls: the frontier word is one line for the whole chip */
+            /* (the committer moves the frontier eight columns at a time: a worker within two batches of its turn polls at the short
+             * interval -- a column that commits itself is on the commit chain from the moment the frontier reaches it) */
             const int dist = k - F;
-            if (dist <= 1) slip_sleep_short();
+            if (dist <= 16) slip_sleep_short();
             else { const int reps = dist < 32 ? dist : 32; for (int q = 0; q < reps; q++) slip_sleep(); }
             if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 1; st->dbg_k = k; st->dbg_a = need; st->dbg_b = F; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
         }
@@ -155,11 +157,13 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
     if (tid < SLIP_PP_WORDS) sv[SV_PP + tid] = tid == 11 && kind == 0 ? 0x7FFFFFFF : 0;
     if (tid == SLIP_PP_WORDS) { sv[SV_PPF] = 0; sv[SV_TMP] = 0; sv[SV_TMP2] = 0; }
     /* the full package is a possibility only with the engine running, a committed predecessor and room for the fill */
-    const bool want_full = P.engine && Fl >= 1 && nrows <= SLIP_TAB_CAP - SLIP_ENG_ROWS;
+    /* (a worker that has just seen a multi-limb pivot does not try for the next 64 columns: the values only grow) */
+    const bool want_full = P.engine && Fl >= 1 && nrows <= SLIP_TAB_CAP - SLIP_ENG_ROWS && !(sv[SV_NOENG] > 0 && k - sv[SV_NOENG] < 64);
     SlipPiv Mf = slip_piv_none();
     if (want_full) Mf = slip_ld_piv(&P.piv[Fl - 1]);
     const bool mf_small = want_full && slip_abs(Mf.len) <= 2;
     slip_block_sync();
+    if (want_full && !mf_small && tid == 0) sv[SV_NOENG] = k;
     uint32_t ulimbs = 0, nUc = 0, sB = 0, nB = 0, maxcB = 0, maxzh = 0, maxc = 0, maxubp = 0;
     uint32_t best = kind == 0 ? 0x7FFFFFFFu : 0u;
     uint64_t smin = ~0ull;                      /* smallest |a| (largest: its complement) over this thread's class-S rows */
@@ -432,7 +436,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
         /* this source changes the rows: what the pre-pass found no longer holds (also after this sweep was taken up again behind a
          * full package that came back: pp_fresh is per call, the flags are the column's) */
         if (GATED) { pp_fresh = 0; if (tid == 0 && (sv[SV_PP] || sv[SV_PKGX])) { sv[SV_PP] = 0; if (sv[SV_PKGX]) slip_retract_package(P, k, sv); } }
-        if (GATED && jn >= sv[SV_F2] && P.engine && pp_want && cur_io && !sv[SV_NOK1] && k - Fl <= SLIP_K1_NEAR && jn >= 1 && jn > sv[SV_K1STAMP]      /* (a package of this column, if any, has just been retracted) */
+        if (GATED && jn >= sv[SV_F2] && P.engine && pp_want && cur_io && !sv[SV_NOK1] && !(sv[SV_NOENG] > 0 && k - sv[SV_NOENG] < 64) && k - Fl <= SLIP_K1_NEAR && jn >= 1 && jn > sv[SV_K1STAMP]      /* (a package of this column, if any, has just been retracted) */
             && sv[SV_NROWS] <= SLIP_TAB_CAP) {
             /* this column's turn is near and the next source's L column is not published yet (its worker is still in stage 2):
              * rather than wait for it, hand the column to the chain engine with everything from position jn on still to be
@@ -1197,25 +1201,31 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                     wlA[5 * at + 4] = (ax & 0x3FFu) * (uint32_t) slot;
                 } else if (wantB) wlB[slip_popc64(mB & below)] = (uint32_t) c_r;
                 slip_wave_sync();
+            }
+            /* the candidates' arithmetic is shared by all waves (a class-B candidate is a multi-limb history update with a
+             * division, ~10 us: eight of them on one wave were most of this column's time on the commit chain) */
+            if (lane == 0) { sv[SV_CNT0 + 1] = ncA; sv[SV_CNT0 + 2] = ncB; sv[SV_LISTN] = ok; }
+            slip_block_sync_named(1);            /* the lists are there; the other waves have taken their position snapshot */
+            if (ok) {
                 if (ncA > 0) {
                     const SlipCandOut co = { f_k0, f_k1, f_inf, stage, slotw, nstage, kind };
-                    const int e = slip_mul_rows_any(P, M, BMs ? Ms : slip_piv_digits(P, M), BMs ? 0 : 1, wlA, 0, 1, ncA, Lnl_, (uint32_t *) 0, (uint32_t *) 0, tag, &co);
+                    const int e = slip_mul_rows_any(P, M, BMs ? Ms : slip_piv_digits(P, M), BMs ? 0 : 1, wlA, 0, nw, ncA, Lnl_, (uint32_t *) 0, (uint32_t *) 0, tag, &co);
                     if (e && lane == 0) sv[SV_ERR] = 1;
-                    if (ncA > nstage || diag_cand) slip_vm_drain();
+                    slip_vm_drain();
                 }
-                for (int t = 0; t < ncB; t++) {
+                for (int t = 0; t < ncB; t += nw) {
                     const int e = slip_run_item_out(&P, 2, 0, 0, k, 0, wlB, t, b0, b1, b2);
                     if (e && lane == 0) sv[SV_ERR] = e;
                 }
                 slip_wave_sync();
-                SLIP_TR(5);                      /* 5: the candidates' arithmetic */
             }
+            slip_block_sync_named(2);            /* every candidate is at level k-1 */
+            SLIP_TR(5);                          /* 5: the candidates' arithmetic */
             if (ok && !sv[SV_ERR]) {
-                const CommitArgs ca = { ncand, diag_cand, nA, nLc, ncA + ncB, slotw, 1, nUc_all, U_l, Lb_total, Lnz_, Lnl_, Unz_, Unl_, ppcl };
+                const CommitArgs ca = { ncand, diag_cand, nA, nLc, ncA + ncB, slotw, 0, nUc_all, U_l, Lb_total, Lnz_, Lnl_, Unz_, Unl_, ppcl };
                 search_publish(ca);
             } else {
                 if (lane == 0) { sv[SV_EST] = ok ? SLIPDEV_INTERNAL : -1; if (ok && !st->dbg_who) { st->dbg_who = 110; st->dbg_k = k; st->dbg_a = sv[SV_ERR]; } }      /* the bounds said this could not happen / the full pass */
-                slip_block_sync_named(1);
             }
             if (lane == 0 && ok && !sv[SV_EST]) slip_agent_add_u64(&st->c_short, 1ull);
 #ifdef SLIP_PROFILING
@@ -1230,6 +1240,25 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 f_pos[t] = (uint32_t) pos;
             }
             slip_block_sync_named(1);
+            /* ... then their share of the candidates */
+            const int ncA = sv[SV_CNT0 + 1], ncB = sv[SV_CNT0 + 2];
+            if (sv[SV_LISTN]) {
+                const int slotw = (lm + 5) & ~1;
+                const int nstage = (3 * SLIP_PAT_CAP) / slotw < 30 ? (3 * SLIP_PAT_CAP) / slotw : 30;
+                const uint32_t *wlB = work, *wlA = work + 2 * SLIP_CAND_CAP;
+                if (ncA > wave) {
+                    const SlipCandOut co = { f_k0, f_k1, f_inf, stage, slotw, nstage, kind };
+                    const int e = slip_mul_rows_any(P, M, BMs ? Ms : slip_piv_digits(P, M), BMs ? 0 : 1, wlA, wave, nw, ncA, sv64[SV_LNL / 2], (uint32_t *) 0, (uint32_t *) 0, tag, &co);
+                    if (e && lane == 0) sv[SV_ERR] = 1;
+                    slip_vm_drain();
+                }
+                for (int t = wave; t < ncB; t += nw) {
+                    const int e = slip_run_item_out(&P, 2, 0, 0, k, 0, wlB, t, b0, b1, b2);
+                    if (e && lane == 0) sv[SV_ERR] = e;
+                }
+                slip_wave_sync();
+            }
+            slip_block_sync_named(2);
         }
         slip_block_sync();                       /* the join: wave 0 has published (or given the column to the full pass) */
         ec = sv[SV_EST];
@@ -1933,7 +1962,7 @@ SLIP_DEV void slip_factor_worker(const SlipParams &P, SlipState *st, uint32_t *l
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
     unsigned long long acc[5] = {0, 0, 0, 0, 0};
-    if (tid == 0) sv[SV_CUP] = 0;                /* the committer has not been seen yet */
+    if (tid == 0) { sv[SV_CUP] = 0; sv[SV_NOENG] = 0; }     /* the committer has not been seen yet */
     for (;;) {
         slip_block_sync();
         if (tid == 0) {

@@ -112,7 +112,8 @@ SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *ld
     slip_vm_drain();
     slip_block_sync();
     if (tid == 0) {
-        slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t) ver << 32) | (uint32_t)(k + 1));
+        /* the header also says how much there is to load: rows, candidates, kind (the committer reads it when it polls) */
+        slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t)(ver | ((uint32_t) nrows << 8) | ((uint32_t) ncand << 18)) << 32) | (uint32_t)(k + 1));
         sv[SV_PKGVER] = (int32_t) ver; sv[SV_PKGX] = 1; sv[SV_PKGK] = 0;
     }
     slip_block_sync();
@@ -135,9 +136,9 @@ SLIP_DEV void slip_export_full(const SlipParams &P, const int k, uint32_t *lds, 
     for (int t = tid; t < nrows; t += T) {
         const uint32_t pi = f_npi[t];
         if (pi >> 31) continue;                                 /* pivotal: final, stays with the worker */
-        uint32_t *a = pk + SLIP_PKG_ROWS + pi;
-        slip_st_u32(a, f_row[t]); slip_st_u32(a + SLIP_PKG_FULLMAX, f_k0[t]); slip_st_u32(a + 2 * SLIP_PKG_FULLMAX, f_k1[t]);
-        slip_st_u32(a + 3 * SLIP_PKG_FULLMAX, f_meta[t]);
+        uint32_t *a = pk + SLIP_PKG_ROWS + pi;                  /* four arrays of nnp words, back to back */
+        slip_st_u32(a, f_row[t]); slip_st_u32(a + nnp, f_k0[t]); slip_st_u32(a + 2 * nnp, f_k1[t]);
+        slip_st_u32(a + 3 * nnp, f_meta[t]);
     }
     if (tid < SLIP_PP_WORDS) slip_st_u32(pk + SLIP_PKG_SUMS + tid, (uint32_t) sv[SV_PP + tid]);
     if (tid == SLIP_PP_WORDS) {
@@ -149,7 +150,7 @@ SLIP_DEV void slip_export_full(const SlipParams &P, const int k, uint32_t *lds, 
     slip_vm_drain();
     slip_block_sync();
     if (tid == 0) {
-        slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t) ver << 32) | (uint32_t)(k + 1));
+        slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t)(ver | ((uint32_t)(4 * nnp) << 8) | (1u << 23)) << 32) | (uint32_t)(k + 1));
         sv[SV_PKGVER] = (int32_t) ver; sv[SV_PKGX] = 1; sv[SV_PKGK] = 1;
     }
     slip_block_sync();
@@ -166,7 +167,8 @@ SLIP_DEV void slip_retract_package(const SlipParams &P, const int k, volatile in
 }
 
 /* one candidate: the one-limb value a (nd digits) times rho[k-1] (in registers) -> LDS slot, search key, length */
-template <int D> SLIP_DEV void slip_commit_mul(const WR<D> &Mr, uint32_t a0, uint32_t a1, int nd, dig_t *slotp, int kind, uint64_t *key_out, int *len_out)
+template <int D> SLIP_DEV void slip_commit_mul(const WR<D> &Mr, uint32_t a0, uint32_t a1, int nd, dig_t *slotp, dig_t *slot2, int kind, uint64_t *key_out, int *len_out,
+                                               uint64_t *lo_out)
 {
     const int lane = slip_lane();
     WR<D> Y;
@@ -179,7 +181,7 @@ template <int D> SLIP_DEV void slip_commit_mul(const WR<D> &Mr, uint32_t a0, uin
     }
     const int len = wr_len<D>(Y);
 #pragma unroll
-    for (int q = 0; q < D; q++) { const int c = 64 * q + lane; if (c < ((len + 1) & ~1)) slotp[c] = Y.d[q]; }
+    for (int q = 0; q < D; q++) { const int c = 64 * q + lane; if (c < ((len + 1) & ~1)) { slotp[c] = Y.d[q]; slot2[c] = Y.d[q]; } }
     const uint32_t d1 = len ? wr_digit<D>(Y, len - 1) : 0u, d2 = len >= 2 ? wr_digit<D>(Y, len - 2) : 0u, d3 = len >= 3 ? wr_digit<D>(Y, len - 3) : 0u;
     uint64_t top = ((uint64_t) d1 << 32) | d2;
     const int sh = len ? slip_clz32(d1) : 0;
@@ -188,6 +190,7 @@ template <int D> SLIP_DEV void slip_commit_mul(const WR<D> &Mr, uint32_t a0, uin
     uint64_t key = ((uint64_t) bits << 40) | (top >> 24);
     if (kind == 1) key = ~key;
     *key_out = key; *len_out = len;
+    *lo_out = (uint64_t) slip_readlane(Y.d[0], 0) | ((uint64_t) slip_readlane(Y.d[0], 1) << 32);
 }
 
 SLIP_DEV int slip_bits64(uint64_t v) { return v ? 64 - slip_clz64(v) : 0; }
@@ -273,7 +276,27 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
     slip_block_sync();
     if (tid == 0) slip_agent_store_i32(&st->committer_up, 1);       /* from now on packages are answered */
 #ifdef SLIP_PROFILE_COMMIT
+    /* calibration, in place: what a dependent LDS read, a dependent VALU op and an s_memrealtime stamp cost HERE (shader
+     * cycles and 10 ns ticks) -- slots 20..23 of the phase record */
+    unsigned long long cal_[4] = {0, 0, 0, 0};
+    if (wave == 0) {
+        for (int w = lane; w < 64; w += SLIP_WAVE) misc[w] = (uint32_t)((w * 37 + 11) & 63);
+        slip_wave_sync_lds();
+        uint32_t idx = (uint32_t) lane & 63u;
+        const unsigned long long c0 = slip_clock(), r0 = slip_realtime();
+        for (int r = 0; r < 256; r++) idx = misc[idx];
+        const unsigned long long c1 = slip_clock(), r1 = slip_realtime();
+        uint32_t acc = idx;
+        for (int r = 0; r < 1024; r++) acc = acc * 3u + 1u;
+        const unsigned long long c2 = slip_clock(), r2 = slip_realtime();
+        unsigned long long r3 = r2;
+        for (int r = 0; r < 64; r++) r3 += slip_realtime() & 1ull;
+        const unsigned long long c3 = slip_clock();
+        if (acc == 0x12345u) misc[0] = (uint32_t) r3;
+        cal_[0] = ((c1 - c0) << 32) | (r1 - r0); cal_[1] = ((c2 - c1) << 32) | (r2 - r1); cal_[2] = c3 - c2;
+    }
     unsigned long long tq_ = slip_realtime(), tacc_[24] = {0};
+    tacc_[20] = cal_[0]; tacc_[21] = cal_[1]; tacc_[22] = cal_[2];
 #define SLIP_CT(i) do { if (tid == 0) { const unsigned long long n_ = slip_realtime(); tacc_[i] += n_ - tq_; tq_ = n_; } } while (0)
 #else
 #define SLIP_CT(i) do { } while (0)
@@ -326,9 +349,9 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 const int j = kc + lane;
                 uint64_t h = 0;
                 if (lane < SLIP_CB && j < P.k_stop && (stop >> 8) > (int64_t) j) h = slip_ld_u64((const uint64_t *)(P.pkg + (int64_t)(j % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_HDR));
-                const uint32_t hv = (uint32_t)(h >> 32);
+                const uint32_t hw_ = (uint32_t)(h >> 32), hv = hw_ & 0xFFu;        /* version; above it the sizes of the package */
                 const int rdy = (uint32_t) h == (uint32_t)(j + 1) && hv >= 2u && !(hv & 1u) && !(j == sv[C_REJ] && hv == (uint32_t) sv[C_REJV]);
-                if (lane < SLIP_CB) hver[lane] = hv;
+                if (lane < SLIP_CB) { hver[lane] = hv; hver[SLIP_CB + lane] = hw_; }
                 const int nb = slip_ctz64(~slip_ballot(rdy));
                 if (nb >= 1) { go = nb < SLIP_CB ? nb : SLIP_CB; break; }
                 slip_sleep_short();
@@ -357,32 +380,70 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             else if (lane == 20) cb[20] = slip_ld_u32(pk + SLIP_PKG_WORKER);
             else if (lane == 21) cb[21] = slip_ld_u32(pk + SLIP_PKG_KIND);
             else if (lane == 22) cb[22] = slip_ld_u32(pk + SLIP_PKG_NFULL);
-            for (int c = lane; c < 6 * SLIP_PKG_CANDS; c += SLIP_WAVE) cb[32 + c] = slip_ld_u32(pk + SLIP_PKG_CAND + c);
-            for (int c = lane; c < 512; c += SLIP_WAVE) cb[128 + c] = slip_ld_u32(pk + SLIP_PKG_ROWS + c);
+            {
+                const uint32_t hw_ = hver[SLIP_CB + i];
+                int nload = (int)((hw_ >> 8) & 0x3FFu), ncl = 6 * (int)((hw_ >> 18) & 0x1Fu);
+                if (nload > 512) nload = 512;
+                if (ncl > 6 * SLIP_PKG_CANDS) ncl = 6 * SLIP_PKG_CANDS;
+                for (int c = lane; c < ncl; c += SLIP_WAVE) cb[32 + c] = slip_ld_u32(pk + SLIP_PKG_CAND + c);
+                for (int c = lane; c < nload; c += SLIP_WAVE) cb[128 + c] = slip_ld_u32(pk + SLIP_PKG_ROWS + c);
+            }
             /* the header again, behind the contents (seqlock): a package that is being rewritten is offered again later */
             const uint64_t h2 = slip_ld_u64((const uint64_t *)(pk + SLIP_PKG_HDR));
             slip_wave_sync_lds();
             const int kindp = (int) cb[21];
             const int nrows = (int) cb[16], ncand = (int) cb[1], stamp = (int) cb[14], stamp0 = (int) cb[15];
-            int hit = (uint32_t) h2 != (uint32_t)(j + 1) || (uint32_t)(h2 >> 32) != hver[i] || cb[19] != hver[i] || cb[20] >= (uint32_t) P.nworkers
+            int hit = (uint32_t) h2 != (uint32_t)(j + 1) || (uint32_t)(h2 >> 32) != hver[SLIP_CB + i] || cb[19] != hver[i] || cb[20] >= (uint32_t) P.nworkers
                       || stamp < stamp0 || stamp > j || stamp0 < sv[C_RING0] || j - stamp0 > SLIP_CB_RING - SLIP_CB - 1;
             if (kindp == 0) {
-                if (nrows < 1 || nrows > SLIP_PKG_NROWMAX || ncand < 1 || ncand > SLIP_PKG_CANDS || cb[12] != 0) hit = 1;
+                if (nrows < 1 || nrows > SLIP_PKG_NROWMAX || ncand < 1 || ncand > SLIP_PKG_CANDS || cb[12] != 0 || (hver[SLIP_CB + i] >> 8) != (uint32_t)(nrows | (ncand << 10))) hit = 1;
                 if (!hit && lane < ncand && cb[32 + 6 * lane + 5] != hver[i]) hit = 1;
-                if (!hit && !mirror) {
+                const uint32_t *rows = cb + 128;
+                if (!hit) {
                     /* the rows against the pivots its worker has not seen (those committed before this batch) */
-                    const uint32_t *rows = cb + 128;
-                    uint32_t rr[SLIP_PKG_NROWMAX / SLIP_WAVE];
+                    if (mirror) {
+                        for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE && 64 * q < nrows; q++) {
+                            const int t = lane + 64 * q;
+                            if (t < nrows) { const int p_ = (int) pinvm[rows[t]]; if (p_ >= stamp && p_ < kc) hit = 1; }
+                        }
+                    } else {
+                        uint32_t rr[SLIP_PKG_NROWMAX / SLIP_WAVE];
 #pragma unroll
-                    for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) rr[q] = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
-                    for (int c = stamp; c < kc; c++) {
-                        const uint32_t r = ring_row[c & (SLIP_CB_RING - 1)];
+                        for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) rr[q] = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
+                        for (int c = stamp; c < kc; c++) {
+                            const uint32_t r = ring_row[c & (SLIP_CB_RING - 1)];
 #pragma unroll
-                        for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) if (rr[q] == r) hit = 1;
+                            for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) if (rr[q] == r) hit = 1;
+                        }
                     }
                 }
+                if (!slip_ballot(hit)) {
+                    /* for the serial step: every candidate's ROW and its position as the reference has it at column kc (the mirror,
+                     * or the value the worker read at frontier stamp0 and where the LAST swap since then that displaced the row put
+                     * it); which candidate is the diagonal row */
+                    const uint32_t myrow = lane < ncand ? rows[cb[32 + 6 * lane]] : 0xFFFFFFFFu;
+                    uint32_t mypos = 0x7FFFFFFFu;
+                    if (mirror) { if (lane < ncand) mypos = (uint32_t) pinvm[myrow]; }
+                    else {
+                        int last = -1;
+                        for (int e0 = stamp0; e0 < kc; e0 += SLIP_WAVE) {
+                            const int e = e0 + lane;
+                            const uint32_t d = e < kc ? ring_disp[e & (SLIP_CB_RING - 1)] : 0xFFFFFFFEu;
+                            for (int c = 0; c < ncand; c++) {
+                                const uint64_t m = slip_ballot(d == slip_readlane(myrow, c));
+                                if (m && lane == c) last = e0 + 63 - slip_clz64(m);
+                            }
+                        }
+                        if (lane < ncand) mypos = last >= 0 ? ring_opos[last & (SLIP_CB_RING - 1)] : cb[32 + 6 * lane + 4];
+                    }
+                    const int diag_t = (int) cb[13] - 1;
+                    const uint64_t dm = slip_ballot(lane < ncand && (int) cb[32 + 6 * lane] == diag_t);
+                    slip_wave_sync_lds();
+                    if (lane < ncand) { cb[32 + 6 * lane] = myrow; cb[32 + 6 * lane + 4] = mypos; }
+                    if (lane == 0) cb[23] = (uint32_t)(diag_t < 0 ? 0xFFu : (dm ? (uint32_t) slip_ctz64(dm) : 0xFEu));      /* 0xFF: no diagonal row; 0xFE: it is not among the candidates */
+                }
             } else if (kindp == 1) {
-                if (!mirror || (int) cb[22] < 1 || (int) cb[22] > SLIP_PKG_FULLMAX || stamp0 < 1 || stamp0 - 1 < sv[C_PR0]) hit = 1;
+                if (!mirror || (int) cb[22] < 1 || (int) cb[22] > SLIP_PKG_FULLMAX || stamp0 < 1 || stamp0 - 1 < sv[C_PR0] || (hver[SLIP_CB + i] >> 8) != (uint32_t)(4 * (int) cb[22]) + (1u << 15)) hit = 1;
             } else hit = 1;
             if (slip_ballot(hit) && lane == 0) cb[18] = 1u;
         }
@@ -405,111 +466,110 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         /* (c) the columns of the batch, one after the other, by wave 0 on LDS only */
         if (wave == 0) {
             int nbc = 0, rej = -1;
+            /* what the chain carries from column to column lives in registers: the slab cursors, rho[j-1]'s record, the swaps of
+             * this batch (lane e: column kc + e).  LDS is touched with whole-wave reads only (a dependent LDS round trip is
+             * 30-40 ns here, and the old code made a hundred of them per column). */
+            int64_t Lnz_ = sv64[SV_LNZ / 2], Lnl_ = sv64[SV_LNL / 2], Unz_ = sv64[SV_UNZ / 2], Unl_ = sv64[SV_UNL / 2];
+            SlipPiv M = *Mrec;
+            uint32_t bs_row = 0xFFFFFFFFu, bs_disp = 0xFFFFFFFFu, bs_opos = 0xFFFFFFFFu;
+            const int xcap_ = P.xcap, wcapP = P.wcap, invcap_ = P.invcap, limb_cap_ = P.limb_cap, nworkers_ = P.nworkers;
+            const int64_t Lcap_nz_ = P.Lcap_nz, Lcap_nl_ = P.Lcap_nl, Ucap_nz_ = P.Ucap_nz, Ucap_nl_ = P.Ucap_nl;
+            uint32_t *const mbox0 = P.pkg + (int64_t) nworkers_ * SLIP_PKG_WORDS;
             for (int i = 0; i < nb; i++) {
-                const int j = kc + i, col = P.q[j];
+                const int j = kc + i;
                 uint32_t *cb = cbuf + i * SLIP_CBW;
                 uint32_t *pb = pub + i * SLIP_PUBW;
                 const uint32_t *cands = cb + 32, *rows = cb + 128;
-                uint32_t *mbx = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t)(cb[20] < (uint32_t) P.nworkers ? cb[20] : 0u) * SLIP_MBOX_WORDS;     /* the worker's mailbox */
-                const int nrows = (int) cb[16], ncand = (int) cb[1], stamp = (int) cb[14], stamp0 = (int) cb[15], kindp = (int) cb[21];
-                const SlipPiv M = *Mrec;
+                /* the header in one read; its fields through the scalar unit */
+                const uint32_t hdr = lane < 32 ? cb[lane] : 0u;
+#define HF(w) ((int) slip_readlane(hdr, (w)))
+                const int nrows = HF(16), ncand = HF(1), stamp0 = HF(15), kindp = HF(21);
+                uint32_t *mbx = mbox0 + (int64_t)((uint32_t) HF(20) < (uint32_t) nworkers_ ? HF(20) : 0) * SLIP_MBOX_WORDS;     /* the worker's mailbox */
                 const int lm = slip_abs(M.len), brho = M.bits, slot = (lm + 3) >> 1;
                 const int slotw = (lm + 5) & ~1;
-                const int64_t Lnz_ = sv64[SV_LNZ / 2], Lnl_ = sv64[SV_LNL / 2], Unz_ = sv64[SV_UNZ / 2], Unl_ = sv64[SV_UNL / 2];
                 dig_t *sl = stage + i * SLIP_CB_SLOTW;
-                int reject = (int) cb[18];                      /* 1: offered again / the worker's business; 2: for good */
+                int reject = HF(18);                            /* 1: offered again / the worker's business; 2: for good */
                 /* what both kinds leave for the publish step */
                 int e_pivrow = 0, e_pivpos = 0, lp_ = 0, pneg = 0, pbits = 0, nUc_all = 0, nLc = 0, nfin = 0, nlate = 0;
-                uint64_t U_l = 0, Lb_total = 0, plimbs = 0, lalloc = 0; int64_t poff = 0;
+                uint64_t U_l = 0, Lb_total = 0, plimbs = 0, lalloc = 0, plo = 0; int64_t poff = 0;
                 unsigned long long ec_src = 0, ec_read = 0, ec_str = 0, ec_upd = 0, ec_mac = 0;
                 /* the row at position j (the one the pivot changes places with): as loaded at the start of the batch, or the row a
                  * swap of this batch displaced to j */
-                int intermed2 = (int) cb[17];
-                {
-                    const int e = kc + lane;
-                    const uint64_t m = slip_ballot(e < j && (int) ring_opos[e & (SLIP_CB_RING - 1)] == j);
-                    if (m) intermed2 = (int) ring_disp[(kc + 63 - slip_clz64(m)) & (SLIP_CB_RING - 1)];
-                }
+                int intermed2 = HF(17);
+                for (int e = 0; e < i; e++) if ((int) slip_readlane(bs_opos, e) == j) intermed2 = (int) slip_readlane(bs_disp, e);
                 SLIP_CT(10);
                 if (!reject && kindp == 0) {
                     /* ---- kind 0: candidates only ---- */
-                    const int nS = (int) cb[2], nB = (int) cb[6];
-                    nUc_all = (int) cb[3]; U_l = (uint64_t) cb[4];
+                    const int nS = HF(2), nB = HF(6);
+                    nUc_all = HF(3); U_l = (uint64_t)(uint32_t) HF(4);
                     const int nA = lm > 2 ? nS : 0;
-                    const int maxc = (int) cb[9] - SLIP_PP_BIAS + brho;
-                    const int maxub_all = maxc > (int) cb[10] ? maxc : (int) cb[10];
-                    const uint64_t L_b = (uint64_t) cb[5] + (uint64_t) nB * (uint64_t)((brho + 63) >> 6) + (lm <= 2 ? 2ull * (uint64_t) nS : 0ull);
+                    const int maxc = HF(9) - SLIP_PP_BIAS + brho;
+                    const int maxub_all = maxc > HF(10) ? maxc : HF(10);
+                    const uint64_t L_b = (uint64_t)(uint32_t) HF(5) + (uint64_t) nB * (uint64_t)((brho + 63) >> 6) + (lm <= 2 ? 2ull * (uint64_t) nS : 0ull);
                     const uint64_t preserve = (uint64_t)((maxub_all + 63) >> 6) + 1;
                     Lb_total = (uint64_t) nA * (uint64_t) slot + preserve + L_b;
                     const uint64_t Ub_total = U_l + preserve;
                     nLc = nrows - nUc_all;
-                    /* a row of the pattern that has become pivotal since the worker looked: the package goes back */
+                    /* this lane's rows and its candidate: one round of reads */
+                    uint32_t rr[SLIP_PKG_NROWMAX / SLIP_WAVE];
+#pragma unroll
+                    for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) rr[q] = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
+                    const bool isc = lane < ncand;
+                    const uint32_t c_row = isc ? cands[6 * lane] : 0xFFFFFFFFu, c_a0 = isc ? cands[6 * lane + 1] : 0u, c_a1 = isc ? cands[6 * lane + 2] : 0u;
+                    const uint32_t c_ax = isc ? cands[6 * lane + 3] : 0u;
+                    uint32_t mypos = isc ? cands[6 * lane + 4] : BIG;
+                    /* a row of the pattern that has become pivotal in this batch: the package goes back (the pivots before the
+                     * batch were checked when it was loaded) */
                     {
                         int hit = 0;
-                        for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) {
-                            const int t = lane + 64 * q;
-                            if (t >= nrows) continue;
-                            const uint32_t rq = rows[t];
-                            if (mirror) { const int p = (int) pinvm[rq]; if (p >= stamp && p < j) hit = 1; }
-                            else for (int c = kc; c < j; c++) if (ring_row[c & (SLIP_CB_RING - 1)] == rq) hit = 1;
+                        for (int e = 0; e < i; e++) {
+                            const uint32_t r = slip_readlane(bs_row, e), d = slip_readlane(bs_disp, e), o = slip_readlane(bs_opos, e);
+#pragma unroll
+                            for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) if (rr[q] == r) hit = 1;
+                            if (c_row == d) mypos = o;          /* ... and a candidate a swap of this batch displaced */
                         }
                         if (slip_ballot(hit)) reject = 1;
                     }
                     SLIP_CT(11);
                     if (!reject) {
-                        const bool A_ok = lm + 2 <= P.xcap && lm + 2 <= 256;
+                        const bool A_ok = lm + 2 <= xcap_ && lm + 2 <= 256;
                         if (lm > SLIP_CB_SLOTW - 6 || slotw > SLIP_CB_SLOTW || (lm > 2 && !A_ok)) reject = 2;
                         if (nB > 0) {
-                            const int Wn = (((int) cb[7] - SLIP_PP_BIAS + brho + 31) >> 5) + (((int) cb[8] + 31) >> 5) + 1;
-                            if (Wn > P.wcap || Wn > P.xcap || Wn > P.invcap) reject = 2;
+                            const int Wn = ((HF(7) - SLIP_PP_BIAS + brho + 31) >> 5) + ((HF(8) + 31) >> 5) + 1;
+                            if (Wn > wcapP || Wn > xcap_ || Wn > invcap_) reject = 2;
                         }
-                        if (Lnz_ + nLc > P.Lcap_nz || Lnl_ + (int64_t) Lb_total > P.Lcap_nl) reject = 2;
-                        if (Unz_ + nUc_all + 1 > P.Ucap_nz || Unl_ + (int64_t) Ub_total > P.Ucap_nl) reject = 2;
-                        if (P.limb_cap > 0 && (int)((maxub_all + 63) >> 6) > P.limb_cap) reject = 2;
+                        if (Lnz_ + nLc > Lcap_nz_ || Lnl_ + (int64_t) Lb_total > Lcap_nl_) reject = 2;
+                        if (Unz_ + nUc_all + 1 > Ucap_nz_ || Unl_ + (int64_t) Ub_total > Ucap_nl_) reject = 2;
+                        if (limb_cap_ > 0 && (int)((maxub_all + 63) >> 6) > limb_cap_) reject = 2;
                     }
                     SLIP_CT(12);
                     int bc = 0;
                     if (!reject) {
                         /* the candidates are class-S values: a * rho[j-1] with the same rho for all, so |a| decides
                          * (slip_get_smallest_pivot.c:58-101 / slip_get_largest_pivot.c); equal values by pattern position */
-                        const uint64_t av = lane < ncand ? ((uint64_t) cands[6 * lane + 1] | ((uint64_t) cands[6 * lane + 2] << 32)) : 0ull;
-                        const uint64_t mykey = lane < ncand ? (kind == 0 ? av : ~av) : ~0ull;
+                        const uint64_t av = (uint64_t) c_a0 | ((uint64_t) c_a1 << 32);
+                        const uint64_t mykey = isc ? (kind == 0 ? av : ~av) : ~0ull;
                         const uint32_t mh = slip_wave_min_u32((uint32_t)(mykey >> 32));
                         const uint32_t ml = slip_wave_min_u32((uint32_t)(mykey >> 32) == mh ? (uint32_t) mykey : 0xFFFFFFFFu);
                         const uint64_t mk = ((uint64_t) mh << 32) | ml;
-                        const uint64_t tie = slip_ballot(lane < ncand && mykey == mk);
-                        /* the candidates' positions (pinv as the reference has it at column j): the mirror, or the value the worker read
-                         * at frontier stamp0 and where the LAST swap since then that displaced the row put it */
-                        uint32_t mypos = BIG;
-                        if (mirror) { if (lane < ncand) mypos = (uint32_t) pinvm[rows[cands[6 * lane]]]; }
-                        else {
-                            const uint32_t myrow = lane < ncand ? rows[cands[6 * lane]] : 0xFFFFFFFFu;
-                            int last = -1;
-                            for (int e0 = stamp0; e0 < j; e0 += SLIP_WAVE) {
-                                const int e = e0 + lane;
-                                const uint32_t d = e < j ? ring_disp[e & (SLIP_CB_RING - 1)] : 0xFFFFFFFEu;
-                                for (int c = 0; c < ncand; c++) {
-                                    const uint64_t m = slip_ballot(d == slip_readlane(myrow, c));
-                                    if (m && lane == c) last = e0 + 63 - slip_clz64(m);
-                                }
-                            }
-                            if (lane < ncand) mypos = last >= 0 ? ring_opos[last & (SLIP_CB_RING - 1)] : cands[6 * lane + 4];
-                        }
-                        if (lane < SLIP_PKG_CANDS) ck_pos[lane] = mypos;
-                        const uint32_t bp = slip_wave_min_u32(((tie >> lane) & 1ull) ? mypos : BIG);
-                        const uint64_t bm_ = slip_ballot(((tie >> lane) & 1ull) && mypos == bp);
-                        int est = bm_ ? 0 : SLIPDEV_INTERNAL;
-                        bc = bm_ ? slip_ctz64(bm_) : 0;
+                        const uint64_t tie = slip_ballot(isc && mykey == mk);
+                        int est = 0;
+                        if (slip_popc64(tie) > 1) {
+                            const uint32_t bp = slip_wave_min_u32(((tie >> lane) & 1ull) ? mypos : BIG);
+                            const uint64_t bm_ = slip_ballot(((tie >> lane) & 1ull) && mypos == bp);
+                            est = bm_ ? 0 : SLIPDEV_INTERNAL;
+                            bc = bm_ ? slip_ctz64(bm_) : 0;
+                        } else if (tie) bc = slip_ctz64(tie);
+                        else est = SLIPDEV_INTERNAL;
                         /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); the worker listed the diagonal row when it is
                          * a nonzero non-pivotal row of the pattern; the common factor rho[j-1] cancels in the ratio */
-                        const int diag_t = (int) cb[13] - 1;
-                        if (!est && diagpref && diag_t >= 0 && (int) cands[6 * bc] != diag_t) {
-                            const uint64_t dm = slip_ballot(lane < ncand && (int) cands[6 * lane] == diag_t);
-                            const int dc = dm ? slip_ctz64(dm) : -1;
-                            if (dc < 0) est = -1;                       /* not among the candidates it sent: the worker decides */
+                        const int dc = HF(23);
+                        if (!est && diagpref && dc != 0xFF && dc != bc) {
+                            if (dc == 0xFE) est = -1;                   /* not among the candidates it sent: the worker decides */
                             else if (scheme == 1 || P.tol_mode == 0) bc = dc;
                             else {
-                                const uint64_t ab = (uint64_t) cands[6 * bc + 1] | ((uint64_t) cands[6 * bc + 2] << 32), ad = (uint64_t) cands[6 * dc + 1] | ((uint64_t) cands[6 * dc + 2] << 32);
+                                const uint64_t ab = (uint64_t) slip_readlane(c_a0, bc) | ((uint64_t) slip_readlane(c_a1, bc) << 32);
+                                const uint64_t ad = (uint64_t) slip_readlane(c_a0, dc) | ((uint64_t) slip_readlane(c_a1, dc) << 32);
                                 const int tk = slip_tol_small(P.tol_m, P.tol_e, scheme == 3 ? ab : ad, scheme == 3 ? ad : ab);
                                 if (tk < 0) est = -1; else if (tk) bc = dc;
                             }
@@ -519,25 +579,24 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     }
                     SLIP_CT(13);
                     if (!reject) {
-                        /* rho[j] = the pivot's one-limb value times rho[j-1] */
-                        const uint32_t a0 = cands[6 * bc + 1], a1 = cands[6 * bc + 2], ax = cands[6 * bc + 3];
+                        /* rho[j] = the pivot's one-limb value times rho[j-1]: into the stage slot (for the publish step) and into Ms */
+                        const uint32_t a0 = slip_readlane(c_a0, bc), a1 = slip_readlane(c_a1, bc), ax = slip_readlane(c_ax, bc);
                         const int nd = (int)((ax >> 12) & 3u);
                         if (lm <= 2) {
                             const slip_u128 y = (slip_u128)((uint64_t) a0 | ((uint64_t) a1 << 32)) * M.lo;
-                            pbits = slip_bits128(y); lp_ = (pbits + 31) >> 5;
-                            if (lane == 0) { sl[0] = (uint32_t) y; sl[1] = (uint32_t)(y >> 32); sl[2] = (uint32_t)(y >> 64); sl[3] = (uint32_t)(y >> 96); }
+                            pbits = slip_bits128(y); lp_ = (pbits + 31) >> 5; plo = (uint64_t) y;
+                            if (lane < 4) { const uint32_t dgt = (uint32_t)(y >> (32 * lane)); sl[lane] = dgt; Ms[lane] = dgt; }
                         } else {
                             const int Dm = (lm + 2 + 63) >> 6;
                             uint64_t key; int len;
-                            if (Dm <= 1) slip_commit_mul<1>(wr_load<1>(Ms, lm), a0, a1, nd, sl, kind, &key, &len);
-                            else if (Dm == 2) slip_commit_mul<2>(wr_load<2>(Ms, lm), a0, a1, nd, sl, kind, &key, &len);
-                            else if (Dm == 3) slip_commit_mul<3>(wr_load<3>(Ms, lm), a0, a1, nd, sl, kind, &key, &len);
-                            else slip_commit_mul<4>(wr_load<4>(Ms, lm), a0, a1, nd, sl, kind, &key, &len);
+                            if (Dm <= 1) slip_commit_mul<1>(wr_load<1>(Ms, lm), a0, a1, nd, sl, Ms, kind, &key, &len, &plo);
+                            else if (Dm == 2) slip_commit_mul<2>(wr_load<2>(Ms, lm), a0, a1, nd, sl, Ms, kind, &key, &len, &plo);
+                            else if (Dm == 3) slip_commit_mul<3>(wr_load<3>(Ms, lm), a0, a1, nd, sl, Ms, kind, &key, &len, &plo);
+                            else slip_commit_mul<4>(wr_load<4>(Ms, lm), a0, a1, nd, sl, Ms, kind, &key, &len, &plo);
                             if (kind == 1) key = ~key;
                             pbits = (int)(key >> 40); lp_ = len;
                         }
-                        slip_wave_sync_lds();
-                        e_pivrow = (int) rows[cands[6 * bc]]; e_pivpos = (int) ck_pos[bc];
+                        e_pivrow = (int) slip_readlane(c_row, bc); e_pivpos = (int) slip_readlane(mypos, bc);
                         pneg = (int)((ax >> 14) & 1u) ^ (M.len < 0);
                         plimbs = (uint64_t)((lp_ + 1) >> 1);
                         poff = lm > 2 ? Lnl_ + (int64_t)(ax & 0x3FFu) * slot : Lnl_ + (int64_t) nA * slot;
@@ -548,11 +607,12 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 } else if (!reject && kindp == 1) {
                     /* ---- kind 1: the chain engine ---- */
                     const int nfull = (int) cb[22];
-                    const uint32_t *prow = cb + 128, *pvlo = prow + SLIP_PKG_FULLMAX, *pvhi = pvlo + SLIP_PKG_FULLMAX, *pmeta = pvhi + SLIP_PKG_FULLMAX;
+                    const uint32_t *prow = cb + 128, *pvlo = prow + nfull, *pvhi = pvlo + nfull, *pmeta = pvhi + nfull;
                     const int pr0 = sv[C_PR0];
                     uint32_t lw = (uint32_t) sv[C_LW];
-                    SlipSmallPiv Mp = pring_get(j - 1);
-                    if (j - 1 < pr0 || !Mp.small) reject = 2;
+                    const int col = P.q[j];
+                    SlipSmallPiv Mp; Mp.lo = M.lo; Mp.inv = M.inv64; Mp.ctz = M.ctz; Mp.sgn = M.len < 0 ? -1 : 1; Mp.small = lm <= 2 && lm >= 1; Mp.bits = M.bits;
+                    if (!Mp.small) reject = 2;
                     int nst = nfull;
                     uint32_t lsrc[4] = {BIG, BIG, BIG, BIG};
                     if (!reject) {
@@ -566,7 +626,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                         for (int q = 0; q < 2; q++) { const int t = lane + 64 * q; if (t < nfull) est_insert(prow[t], t); }
                         slip_wave_sync_lds();
                         /* E2: the rows that have become pivotal since the export are the sources still to be applied */
-                        for (int q = 0; q < 4; q++) {
+                        for (int q = 0; q < 4 && 64 * q < nst; q++) {
                             const int t = lane + 64 * q;
                             if (t < nst) { const uint32_t p = (uint32_t) pinvm[est_row[t]]; if ((int) p < j) lsrc[q] = p; }
                         }
@@ -625,14 +685,15 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                         const int hj = (int)(mj & 0x3FFFFFFFu) - 1;
                         /* bring x[j] to its final value: history update to level c-1 (:139-149) */
                         if (sj != 0 && hj < c - 1) {
-                            slip_u128 y = (slip_u128) xj * Dv.lo; sj *= Dv.sgn;
+                            const slip_u128 y = (slip_u128) xj * Dv.lo; sj *= Dv.sgn;
                             if (hj >= 0) {
                                 const SlipSmallPiv H = pring_get(hj);
-                                if (hj < pr0 || !H.small) { reject = 2; break; }
-                                y = slip_divexact128(y, H.lo, H.ctz, H.inv); sj *= H.sgn;
+                                if (hj < pr0 || !H.small || slip_bits128(y) - H.bits + 1 > 64) { reject = 2; break; }
+                                xj = slip_divexact_to64(y, H.ctz, H.inv); sj *= H.sgn;      /* the quotient fits one limb: one multiply */
+                            } else {
+                                if ((uint64_t)(y >> 64)) { reject = 2; break; }
+                                xj = (uint64_t) y;
                             }
-                            if ((uint64_t)(y >> 64)) { reject = 2; break; }
-                            xj = (uint64_t) y;
                         }
                         slip_wave_sync_lds();                        /* every lane has read the row before one lane rewrites it */
                         if (lane == 0) { est_vlo[jt] = (uint32_t) xj; est_vhi[jt] = (uint32_t)(xj >> 32); est_meta[jt] = (sj < 0 ? 0x80000000u : 0u) | 0x40000000u | (uint32_t)(hj + 1); }
@@ -675,28 +736,28 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                                 had_x = lx;
                                 SlipSmallPiv H; H.lo = 1; H.inv = 1; H.ctz = 0; H.sgn = 1; H.small = 1; H.bits = 1;
                                 if (hdiv) { H = pring_get(hi_); if (hi_ < pr0 || !H.small) ovf = 1; }
-                                const int bxi = slip_bits64(xi);
-                                const int bxp = !lx ? 0 : (!hist ? bxi : (hdiv ? bxi + Dv.bits - H.bits + 1 : bxi + Dv.bits));
-                                const int b1b = lx ? bxp + R.bits : 0, b2b = slip_bits64(lv) + bxj;
+                                /* hist(x_i) = x_i * rho[c-1] / rho[h] must fit one limb, like every value the engine keeps */
+                                uint64_t yh = xi; int s1 = si * R.sgn;
+                                if (hist) {
+                                    const slip_u128 y = (slip_u128) xi * Dv.lo; s1 *= Dv.sgn;
+                                    if (hdiv) {
+                                        if (slip_bits128(y) - H.bits + 1 > 64) ovf = 1;
+                                        yh = slip_divexact_to64(y, H.ctz, H.inv); s1 *= H.sgn;
+                                    } else { if ((uint64_t)(y >> 64)) ovf = 1; yh = (uint64_t) y; }
+                                }
+                                const int b1b = lx ? slip_bits64(yh) + R.bits : 0, b2b = slip_bits64(lv) + bxj;
                                 if ((b1b > b2b ? b1b : b2b) + 1 > 126) ovf = 1;
                                 if (!ovf) {
-                                    slip_u128 y = 0; int s1 = si * R.sgn;
-                                    if (lx) {
-                                        y = (slip_u128) xi;
-                                        if (hist) { y *= Dv.lo; s1 *= Dv.sgn; }
-                                        if (hdiv) { y = slip_divexact128(y, H.lo, H.ctz, H.inv); s1 *= H.sgn; }
-                                        y *= R.lo;
-                                    }
+                                    const slip_u128 y = lx ? (slip_u128) yh * R.lo : (slip_u128) 0;
                                     const slip_u128 p2 = (slip_u128) lv * xj;
                                     const int s2 = ((w0 >> 31) ? -1 : 1) * sj;
                                     slip_u128 mag; int sT;
                                     if (!lx) { mag = p2; sT = -s2; }
                                     else if (s1 == s2) { if (y >= p2) { mag = y - p2; sT = s1; } else { mag = p2 - y; sT = -s1; } }
                                     else { mag = y + p2; sT = s1; }
-                                    mag = slip_divexact128(mag, Dv.lo, Dv.ctz, Dv.inv); sT *= Dv.sgn;      /* c >= 1 here */
-                                    if ((uint64_t)(mag >> 64)) ovf = 1;
+                                    if (mag != 0 && slip_bits128(mag) - Dv.bits + 1 > 64) ovf = 1;      /* c >= 1 here: the division by rho[c-1] */
                                     else {
-                                        const uint64_t nv = (uint64_t) mag;
+                                        const uint64_t nv = slip_divexact_to64(mag, Dv.ctz, Dv.inv); sT *= Dv.sgn;
                                         est_vlo[idx] = (uint32_t) nv; est_vhi[idx] = (uint32_t)(nv >> 32);
                                         est_meta[idx] = (nv && sT < 0 ? 0x80000000u : 0u) | (uint32_t)(c + 1);
                                     }
@@ -708,7 +769,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                             }
                             if (slip_ballot(ovf)) { reject = 2; break; }
                             slip_wave_sync_lds();
-                            for (int q = 0; q < 4; q++) {                       /* a filled-in row may itself have become pivotal meanwhile: a later source */
+                            for (int q = nst_old >> 6; q < 4 && 64 * q < nst; q++) {       /* a filled-in row may itself have become pivotal meanwhile: a later source */
                                 const int t = lane + 64 * q;
                                 if (t >= nst_old && t < nst) { const uint32_t p = (uint32_t) pinvm[est_row[t]]; lsrc[q] = (int) p < j ? p : BIG; }
                             }
@@ -719,9 +780,9 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     int pt = -1;
                     if (!reject) {
                         uint64_t fin[4]; int fneg[4], isL[4]; int ovf = 0;
-                        for (int q = 0; q < 4; q++) {
+                        for (int q = 0; q < 4; q++) { fin[q] = 0; fneg[q] = 0; isL[q] = 0; }
+                        for (int q = 0; q < 4 && 64 * q < nst; q++) {
                             const int t = lane + 64 * q;
-                            fin[q] = 0; fneg[q] = 0; isL[q] = 0;
                             if (t < nst) {
                                 const uint32_t m = est_meta[t];
                                 if (!((m >> 30) & 1u)) {
@@ -730,13 +791,12 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                                     if (x) {
                                         int s_ = (m >> 31) ? -1 : 1; const int h = (int)(m & 0x3FFFFFFFu) - 1;
                                         if (h < j - 1) {
-                                            slip_u128 y = (slip_u128) x * Mp.lo; s_ *= Mp.sgn;
+                                            const slip_u128 y = (slip_u128) x * Mp.lo; s_ *= Mp.sgn;
                                             if (h >= 0) {
                                                 const SlipSmallPiv H = pring_get(h);
-                                                if (h < pr0 || !H.small) ovf = 1; else { y = slip_divexact128(y, H.lo, H.ctz, H.inv); s_ *= H.sgn; }
-                                            }
-                                            if ((uint64_t)(y >> 64)) ovf = 1;
-                                            x = (uint64_t) y;
+                                                if (h < pr0 || !H.small || slip_bits128(y) - H.bits + 1 > 64) ovf = 1;
+                                                else { x = slip_divexact_to64(y, H.ctz, H.inv); s_ *= H.sgn; }
+                                            } else { if ((uint64_t)(y >> 64)) ovf = 1; x = (uint64_t) y; }
                                         }
                                         fin[q] = x; fneg[q] = s_ < 0;
                                     }
@@ -747,7 +807,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                         if (!reject) {
                             uint64_t Lex = 0; int nLl = 0;
                             uint64_t kmin = ~0ull;
-                            for (int q = 0; q < 4; q++) {
+                            for (int q = 0; q < 4 && 64 * q < nst; q++) {
                                 const int t = lane + 64 * q;
                                 if (isL[q]) { est_vlo[t] = (uint32_t) fin[q]; est_vhi[t] = (uint32_t)(fin[q] >> 32); est_meta[t] = (fneg[q] ? 0x80000000u : 0u) | (uint32_t) j; }
                                 nLl += slip_popc64(slip_ballot(isL[q])); Lex += (uint64_t) slip_popc64(slip_ballot(isL[q] && fin[q] != 0));
@@ -761,7 +821,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                             else {
                                 /* equal values: the earlier pattern position wins (slip_get_smallest_pivot.c:79) */
                                 uint32_t bpos = BIG; int bq = -1;
-                                for (int q = 0; q < 4; q++) {
+                                for (int q = 0; q < 4 && 64 * q < nst; q++) {
                                     const int t = lane + 64 * q;
                                     const uint64_t key = (isL[q] && fin[q]) ? (kind == 0 ? fin[q] : ~fin[q]) : ~0ull;
                                     if (key == mk) { const uint32_t p = (uint32_t) pinvm[est_row[t]]; if (p < bpos) { bpos = p; bq = q; } }
@@ -798,13 +858,13 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                             if (!reject) {
                                 const uint64_t pv = (uint64_t) est_vlo[pt] | ((uint64_t) est_vhi[pt] << 32);
                                 e_pivrow = (int) est_row[pt]; e_pivpos = (int) pinvm[est_row[pt]];
-                                pneg = (int)(est_meta[pt] >> 31); pbits = slip_bits64(pv); lp_ = (pbits + 31) >> 5;
-                                if (lane == 0) { sl[0] = (uint32_t) pv; sl[1] = (uint32_t)(pv >> 32); }
+                                pneg = (int)(est_meta[pt] >> 31); pbits = slip_bits64(pv); lp_ = (pbits + 31) >> 5; plo = pv;
+                                if (lane < 2) { const uint32_t dgt = (uint32_t)(pv >> (32 * lane)); sl[lane] = dgt; Ms[lane] = dgt; }
                                 nfin = nst;
                                 /* the rows go back to the worker: values final, positions as the reference has them at column j (the
                                  * stores are issued here and drained with the batch) */
                                 uint32_t *hb = mbx + SLIP_MBOX_HDR;
-                                for (int q = 0; q < 4; q++) {
+                                for (int q = 0; q < 4 && 64 * q < nst; q++) {
                                     const int t = lane + 64 * q;
                                     if (t < nst) {
                                         const uint32_t m = est_meta[t];
@@ -815,7 +875,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                                 /* L(:,j) as the later columns of the run will read it: into the ring */
                                 {
                                     uint32_t at0 = lw;
-                                    for (int q = 0; q < 4; q++) {
+                                    for (int q = 0; q < 4 && 64 * q < nst; q++) {
                                         const int t = lane + 64 * q;
                                         const uint64_t lm_ = slip_ballot(isL[q]);
                                         if (isL[q]) {
@@ -839,40 +899,48 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 if (lane == 0) fprintf(stderr, "committer: col %d kind %d reject %d pre %d (stamp0 %d nfull %d nrows %d nlate %d pr0 %d ring0 %d)\n", j, kindp, reject, (int) cb[18], stamp0, (int) cb[22], nrows, nlate, sv[C_PR0], sv[C_RING0]);
 #endif
                 if (reject) { rej = j; break; }
-                /* ---- the column is committed: what the next one needs, in LDS; what the publish step needs, in its record ---- */
+                /* ---- the column is committed: what the next one needs stays in registers; the rings and the publish record in LDS ---- */
                 {
                     SlipPiv pr; pr.off = poff; pr.len = pneg ? -lp_ : lp_; pr.bits = pbits; pr.invlen = 0; pr.pad = 0;
-                    pr.lo = (uint64_t) sl[0] | ((uint64_t) sl[1] << 32);
+                    pr.lo = plo;
                     int z = 0;
                     if (lp_ <= 2) z = slip_ctz64(pr.lo);
-                    pr.ctz = z; pr.inv64 = lp_ <= 2 ? slip_inv64(pr.lo >> z) : 0;
+                    pr.ctz = z; pr.inv64 = lp_ <= 2 ? slip_inv64(pr.lo >> z) : 0;      /* (ctz of a long pivot is found while its digits are published; nobody reads it here) */
                     const int64_t nUnz = Unz_ + nUc_all + 1, nLnz = Lnz_ + nLc;
                     const int64_t nUnl = Unl_ + (int64_t)(U_l + plimbs), nLnl = Lnl_ + (int64_t) Lb_total;
-                    /* rho[j] for the next column: LDS to LDS */
-                    if (lp_ <= SLIP_CB_SLOTW - 6) for (int c = lane; c < ((lp_ + 1) & ~1); c += SLIP_WAVE) Ms[c] = sl[c];
+                    M = pr; Lnz_ = nLnz; Lnl_ = nLnl; Unz_ = nUnz; Unl_ = nUnl;
+                    if (lane == i) { bs_row = (uint32_t) e_pivrow; bs_disp = (uint32_t) intermed2; bs_opos = (uint32_t) e_pivpos; }
+#if defined(SLIP_EMULATE) && defined(SLIP_EMU_TRACE)
+                    if (lane == 0) fprintf(stderr, "commit col %d kind %d: pivot row %d from pos %d, row %d goes there\n", j, kindp, e_pivrow, e_pivpos, intermed2);
+#endif
                     if (lane == 0) {
-                        *Mrec = pr;                                      /* (ctz of a long pivot is found while its digits are published; nobody reads it here) */
                         pring_put(j, pr);
-                        sv64[SV_LNZ / 2] = nLnz; sv64[SV_LNL / 2] = nLnl; sv64[SV_UNZ / 2] = nUnz; sv64[SV_UNL / 2] = nUnl;
                         ring_row[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivrow; ring_disp[j & (SLIP_CB_RING - 1)] = (uint32_t) intermed2;
                         ring_opos[j & (SLIP_CB_RING - 1)] = (uint32_t) e_pivpos;
-                        if (j + 1 - sv[C_RING0] > SLIP_CB_RING) sv[C_RING0] = j + 1 - SLIP_CB_RING;
-                        if (j + 1 - sv[C_PR0] > SLIP_CB_RING) sv[C_PR0] = j + 1 - SLIP_CB_RING;
-#if defined(SLIP_EMULATE) && defined(SLIP_EMU_TRACE)
-                        fprintf(stderr, "commit col %d kind %d: pivot row %d from pos %d, row %d (loaded %d) goes there; mirror says row at... pinvm[piv] %d pinvm[im2] %d\n", j, kindp, e_pivrow, e_pivpos, intermed2, (int) cb[17], mirror ? (int) pinvm[e_pivrow] : -1, mirror ? (int) pinvm[intermed2] : -1);
-#endif
                         if (mirror) { pinvm[e_pivrow] = (uint16_t) j; pinvm[intermed2] = (uint16_t) e_pivpos; }
-                        sv[C_LASTPR] = e_pivrow;
-                        pb[0] = (uint32_t) e_pivrow; pb[1] = (uint32_t) e_pivpos; pb[2] = (uint32_t) intermed2; pb[3] = (uint32_t)(pneg ? -lp_ : lp_); pb[4] = (uint32_t) pbits;
-                        pb[5] = (uint32_t) lp_; pb[6] = (uint32_t) nfin; pb[7] = (uint32_t) nlate;
-                        pb[8] = (uint32_t) poff; pb[9] = (uint32_t)((uint64_t) poff >> 32); pb[10] = (uint32_t) lalloc; pb[11] = (uint32_t)(lalloc >> 32);
-                        pb[12] = (uint32_t) nUnz; pb[13] = (uint32_t)((uint64_t) nUnz >> 32); pb[14] = (uint32_t) nLnz; pb[15] = (uint32_t)((uint64_t) nLnz >> 32);
-                        pb[16] = (uint32_t) nUnl; pb[17] = (uint32_t)((uint64_t) nUnl >> 32); pb[18] = (uint32_t) nLnl; pb[19] = (uint32_t)((uint64_t) nLnl >> 32);
-                        pb[20] = cb[20]; pb[21] = (uint32_t) kindp;
                         if (kindp == 1) {
                             eacc[0] += ec_src; eacc[1] += ec_read; eacc[2] += ec_str; eacc[3] += ec_upd; eacc[4] += ec_mac;
                             eacc[5] += 1ull; eacc[6] += (unsigned long long) nlate;
                         }
+                    }
+                    /* the publish record: lane w writes word w */
+                    {
+                        uint32_t v = 0;
+                        const uint32_t wk_ = (uint32_t) HF(20);
+                        switch (lane) {
+                            case 0: v = (uint32_t) e_pivrow; break; case 1: v = (uint32_t) e_pivpos; break; case 2: v = (uint32_t) intermed2; break;
+                            case 3: v = (uint32_t)(pneg ? -lp_ : lp_); break; case 4: v = (uint32_t) pbits; break; case 5: v = (uint32_t) lp_; break;
+                            case 6: v = (uint32_t) nfin; break; case 7: v = (uint32_t) nlate; break;
+                            case 8: v = (uint32_t) poff; break; case 9: v = (uint32_t)((uint64_t) poff >> 32); break;
+                            case 10: v = (uint32_t) lalloc; break; case 11: v = (uint32_t)(lalloc >> 32); break;
+                            case 12: v = (uint32_t) nUnz; break; case 13: v = (uint32_t)((uint64_t) nUnz >> 32); break;
+                            case 14: v = (uint32_t) nLnz; break; case 15: v = (uint32_t)((uint64_t) nLnz >> 32); break;
+                            case 16: v = (uint32_t) nUnl; break; case 17: v = (uint32_t)((uint64_t) nUnl >> 32); break;
+                            case 18: v = (uint32_t) nLnl; break; case 19: v = (uint32_t)((uint64_t) nLnl >> 32); break;
+                            case 20: v = wk_; break; case 21: v = (uint32_t) kindp; break;
+                            default: break;
+                        }
+                        if (lane < 22) pb[lane] = v;
                     }
                     /* the permutation swap (slip_get_pivot.c:164-176) is stored HERE, by this one wave, column after column:
                      * successive columns of a batch write the same words (a row displaced to position p, the next pivot taken from
@@ -895,7 +963,17 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 SLIP_CT(16);
                 nbc = i + 1;
             }
-            if (lane == 0) { sv[C_NBC] = nbc; sv[C_ST] = rej; }
+#undef HF
+            const uint32_t lastpr_ = slip_readlane(bs_row, nbc > 0 ? nbc - 1 : 0);
+            if (lane == 0) {
+                sv[C_NBC] = nbc; sv[C_ST] = rej;
+                if (nbc > 0) {
+                    *Mrec = M; sv64[SV_LNZ / 2] = Lnz_; sv64[SV_LNL / 2] = Lnl_; sv64[SV_UNZ / 2] = Unz_; sv64[SV_UNL / 2] = Unl_;
+                    sv[C_LASTPR] = (int32_t) lastpr_;
+                    if (kc + nbc - sv[C_RING0] > SLIP_CB_RING) sv[C_RING0] = kc + nbc - SLIP_CB_RING;
+                    if (kc + nbc - sv[C_PR0] > SLIP_CB_RING) sv[C_PR0] = kc + nbc - SLIP_CB_RING;
+                }
+            }
         }
         slip_block_sync();
         SLIP_CT(3);                                  /* 3: the serial part */

@@ -30,6 +30,11 @@ for flags in flagsets:
           f"wait {o[0]:.0f} load {o[1]:.0f} serial {o[3]:.0f} publish {o[4]:.0f} verdict {o[5]:.0f} us; per column: serial {o[3] / cols:.2f} "
           f"[setup {o[10] / cols:.2f} rows {o[11] / cols:.2f} cap {o[12] / cols:.2f} choose {o[13] / cols:.2f} mul {o[15] / cols:.2f} "
           f"e1 {o[17] / cols:.2f} e3 {o[18] / cols:.2f} e4 {o[19] / cols:.2f} record {o[16] / cols:.2f}]")
+    f.lib.slip_hip_factor_phase_cycles(f.h, out)
+    c0, c1, c2 = int(out[20]), int(out[21]), int(out[22])
+    if c0:
+        print(f"    calibration in the committer: dependent LDS read {(c0 >> 32) / 256:.0f} cycles = {(c0 & 0xFFFFFFFF) * 10 / 256:.0f} ns; dependent VALU mul-add "
+              f"{(c1 >> 32) / 1024:.1f} cycles = {(c1 & 0xFFFFFFFF) * 10 / 1024:.1f} ns; s_memrealtime stamp {c2 / 64:.0f} cycles; clock {(c1 >> 32) / max((c1 & 0xFFFFFFFF) * 10, 1):.2f} GHz")
     w = np.zeros(2048, np.int32)
     f.lib.slip_hip_factor_debug_words.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     if f.lib.slip_hip_factor_debug_words(f.h, 24 * entry["n"] + 2048, 2048, w.ctypes.data) == 0 and flags == flagsets[0]:
