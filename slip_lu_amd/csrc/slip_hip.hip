@@ -514,6 +514,19 @@ static int32_t default_workers(const slip_hip_factor *f, int32_t xcap, int32_t a
     int per_cu = (int)((160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1));
     const int by_waves = 8 / (f->waves > 0 ? f->waves : 1);           /* 232 VGPRs: two waves per SIMD, eight per CU */
     if (per_cu > by_waves) per_cu = by_waves;
+#ifndef SLIP_EMULATE
+    /* ... and never more than the runtime says can be resident with this launch shape (the default grid is what fits the
+     * chip at once; larger grids asked for explicitly still work -- a workgroup that is not resident holds no ticket) */
+    {
+        int api = 0;
+        const int fast = f->bitmap_in_lds && f->scratch_in_lds;
+        const void *fn = fast ? (const void *) slip_factor_kernel<true> : (const void *) slip_factor_kernel<false>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes) == hipSuccess &&
+            (fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, slip_factor_kernel<true>, 64 * f->waves, (size_t) lds_bytes)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, slip_factor_kernel<false>, 64 * f->waves, (size_t) lds_bytes)) == hipSuccess &&
+            api >= 1 && api < per_cu) per_cu = api;
+    }
+#endif
     if (per_cu < 1) per_cu = 1;
     int64_t w = asked > 0 ? asked : (int64_t) cus * per_cu;
     const int64_t per_worker = (int64_t) f->n * (16 + 4 * (int64_t) xcap + 16) + 4096;

@@ -161,3 +161,35 @@ def check_rescale(lib_path, name, seed, **kw):
 
 def test_emulated_rescale(emu_lib):
     check_rescale(emu_lib, "gen_n40", 5, waves=2, workers=2)
+
+
+@pytest.mark.parametrize("name,waves,workers,seed", [("10teams", 2, 6, 1), ("10teams", 2, 40, 3), ("NSR8K_w600", 2, 6, 3),
+                                                     ("gen_n40_pm1", 2, 5, 1), ("gen_n40", 2, 6, 2)])
+def test_emulated_chain_engine(emu_lib, name, waves, workers, seed):
+    """FULL packages through the committer's chain engine (late sources applied in LDS, rows handed back) on the CPU
+    emulation: the reference's factors and algorithmic counters, and the engine really ran"""
+    import slip_lu_amd as sl
+    entry, fix = load_case(name)
+    set_seed(emu_lib, seed)
+    f = sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], pivot=entry["pivot"], tol=entry["tol"],
+                         limb_cap=entry["cap"], waves=waves, workers=workers, lib_path=emu_lib)
+    try:
+        f.run(entry["kmax"])
+        res = f.download()
+    finally:
+        f.close()
+    check_against_golden(entry, fix, res)
+    assert res["info"]["engine_commits"] > 0, res["info"]
+    if name != "gen_n40":
+        assert res["info"]["engine_sources"] > 0, res["info"]
+
+
+def test_emulated_engine_off_and_candidates_only(emu_lib):
+    """diagnostic flag 8: no full packages -- the candidates-only packages and the worker commits alone"""
+    import slip_lu_amd as sl
+    for name, flags in (("gen_n40", 8), ("gen_n40_pm1", 8), ("test_mat_p4tol", 8), ("gen_n40", 2)):
+        entry, fix = load_case(name)
+        res = sl.factorize(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], pivot=entry["pivot"], tol=entry["tol"],
+                           kmax=entry["kmax"], limb_cap=entry["cap"], waves=2, workers=5, lib_path=emu_lib, debug_flags=flags)
+        check_against_golden(entry, fix, res)
+        assert res["info"]["engine_commits"] == 0

@@ -220,3 +220,60 @@ def test_bench_builds_the_torchrun_command():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[cmd.index("--gpus") + 1] == "2" and "--no-cpu-baseline" in cmd and os.path.basename(cmd[cmd.index("--gpus") - 1]) == "bench.py"
+
+
+WORKER_FARM = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np
+    import slip_lu_amd as sl
+    from slip_lu_amd import parallel
+    import test_subtree_farm as T
+    dist = parallel.init("gloo")
+    rank, world, _ = parallel.env_rank()
+    emu = os.path.join({root!r}, "tests", "emu", "libslip_emu.so")
+    n, Ap, Ai, Ax = T.make_blocked((4, 6, 3, 5, 7), 41)
+    q = np.random.default_rng(42).permutation(n).astype(np.int32)
+    blocks, rest = parallel.leading_blocks(n, Ap, Ai, q, n)
+    assert rest == []
+
+    def make(n_, Ap_, Ai_, Alen_, Alimbs_, q_, **kw):
+        return sl.Factorization(n_, Ap_, Ai_, Alen_, Alimbs_, q_, lib_path=emu, waves=1, workers=2, **kw)
+    # THE function under test, with two ranks: bins[rank], the count gather, done_cols, the device rescale
+    mine, owner, sigma = parallel.farm_factorize(dist, n, Ap, Ai, Ax, q, blocks, make=make)
+    whole = T.as_columns(T.oracle_factor(n, Ap, Ai, Ax, q))
+    assert len(owner) == n and any(s != 1 for s in sigma)
+    done = [0] * len(blocks); ok = 1; checked = 0
+    for k, t in enumerate(owner):
+        kl = done[t]; done[t] += 1
+        if t in mine:
+            loc = T.as_columns_partial(mine[t]); ids = blocks[t]
+            ok &= loc["rho"][kl] == whole["rho"][k]
+            ok &= {{ids[r]: v for r, v in loc["L"][kl].items()}} == whole["L"][k]
+            ok &= {{ids[r]: v for r, v in loc["U"][kl].items()}} == whole["U"][k]
+            checked += 1
+    tot_ok = parallel.sum_over_ranks(dist, int(ok)); tot_cols = parallel.sum_over_ranks(dist, checked)
+    nmine = parallel.sum_over_ranks(dist, len(mine))
+    if rank == 0:
+        print(json.dumps(dict(ok=tot_ok, world=world, cols=tot_cols, blocks=nmine, mine0=len(mine))))
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+''')
+
+
+def test_farm_factorize_two_ranks_gloo():
+    """parallel.farm_factorize ITSELF under torch.distributed with two ranks (gloo; the emulator build stands in for the GPU):
+    every rank factorises its bin of blocks, the pivot chains and the column counts are all-gathered, every rank rescales
+    its columns on the 'device' -- each column of the whole matrix is checked by exactly one rank"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libslip_emu.so"])
+    path = os.path.join("/tmp", f"slip_farm2_worker_{os.getpid()}.py")
+    open(path, "w").write(WORKER_FARM.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", path],
+                         capture_output=True, text=True, env=env, timeout=900)
+    os.unlink(path)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] == 2 and res["world"] == 2 and res["cols"] == 25 and res["blocks"] == 5 and 0 < res["mine0"] < 5, res
