@@ -609,6 +609,65 @@ template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, 
     return slip_store_x_reg<D>(P, r, Y, sign, xr.h, xr.tag);
 }
 
+/* compare the magnitudes of two register numbers: -1, 0, +1 (all lanes call) */
+template <int D> SLIP_DEV int wr_cmp(const WR<D> &A, const WR<D> &B)
+{
+#pragma unroll
+    for (int q = D - 1; q >= 0; q--) {
+        const uint64_t df = slip_ballot(A.d[q] != B.d[q]);
+        if (df) {
+            const int t = 63 - slip_clz64(df);
+            return slip_readlane(A.d[q], t) > slip_readlane(B.d[q], t) ? 1 : -1;
+        }
+    }
+    return 0;
+}
+
+/* Is |x[r] * rho[pm] / rho[pd]| (pd >= 0: the row was last updated at column pd) on the far side of |a * rho[pm]|?  Nothing is
+ * stored: the row keeps its state.  Used by the pre-pass to rule class-B candidates out BEFORE the column's turn: every
+ * candidate's final value is its level-pm value times the same rho[k-1] / rho[pm], so the order at level pm is the final
+ * order.  Returns +1 / 0 / -1 for |B value| > / = / < |a rho[pm]|, or 2 when the widths do not fit the register path.
+ * (The inverse of rho[pd] this leaves in the shared cache is the one the row's final history update needs.) */
+template <int D> SLIP_DEV int slip_cand_compare_reg(const SlipParams &P, int r, int pm, int pd, uint32_t a0, uint32_t a1, int nd, dig_t *b0)
+{
+    const SlipRow xr = P.xrow[r];
+    const int lx = slip_abs(xr.len);
+    const SlipPiv m = slip_ld_piv(&P.piv[pm]);
+    const int lm = slip_abs(m.len);
+    const SlipPiv d = slip_ld_piv(&P.piv[pd]);
+    const int W = (xr.bits + m.bits - d.bits + 1 + 31) >> 5;
+    { const int e = slip_ensure_inv_reg<D>(P, pd, W, b0); if (e) return 2; }
+    const WR<D> M = wr_load_s<D>(slip_piv_digits(P, m), lm);
+    WR<D> X = wr_load_g<D>(P.xd + (int64_t) r * P.xcap, lx);
+    WR<D> Y = lx <= lm ? wr_mul<D>(X, lx < 64 * D ? lx : 64 * D, M) : wr_mul<D>(M, lm < 64 * D ? lm : 64 * D, X);
+    Y = wr_mask<D>(wr_shr<D>(Y, d.ctz, b0), W);
+    const WR<D> I = wr_load_s<D>(P.invd + (int64_t) pd * P.invcap, W);
+    Y = wr_mask<D>(wr_mul<D>(I, W, Y), W);
+    WR<D> A;
+    if (nd == 1) A = wr_mul_digit<D>(a0, M);
+    else {
+        WR<D> S = wr_zero<D>();
+        if (slip_lane() == 0) S.d[0] = a0;
+        if (slip_lane() == 1) S.d[0] = a1;
+        A = wr_mul<D>(S, nd, M);
+    }
+    return wr_cmp<D>(Y, A);
+}
+SLIP_DEVN int slip_cand_compare_out(const SlipParams *Pg, int r, int pm, int pd, uint32_t a0, uint32_t a1, int nd, dig_t *b0)
+{
+    const SlipParams &P = *Pg;
+    const SlipRow xr = P.xrow[r];
+    const SlipPiv m = slip_ld_piv(&P.piv[pm]), d = slip_ld_piv(&P.piv[pd]);
+    /* widths: the shifted product x * rho[pm] and a * rho[pm] must fit the registers */
+    const int Wn = ((xr.bits + m.bits + 31) >> 5) + 1, Wa = slip_abs(m.len) + 2;
+    const int Wmax = Wn > Wa ? Wn : Wa;
+    if (Wmax > 256 || Wn > P.invcap || (xr.bits + m.bits - d.bits + 1 + 31) / 32 > P.invcap) return 2;
+    if (Wmax <= 64)  return slip_cand_compare_reg<1>(P, r, pm, pd, a0, a1, nd, b0);
+    if (Wmax <= 128) return slip_cand_compare_reg<2>(P, r, pm, pd, a0, a1, nd, b0);
+    if (Wmax <= 192) return slip_cand_compare_reg<3>(P, r, pm, pd, a0, a1, nd, b0);
+    return slip_cand_compare_reg<4>(P, r, pm, pd, a0, a1, nd, b0);
+}
+
 SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2, int newh)
 {
     SlipRow xr = P.xrow[r];

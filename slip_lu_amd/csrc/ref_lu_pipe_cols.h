@@ -140,7 +140,7 @@ SLIP_DEV void slip_rlist_push(const SlipParams &P, volatile int32_t *sv, uint32_
  *    level), so that the committer needs no pivot older than the package.  f_k0/f_k1: the value, f_meta: sign | h+1,
  *    f_npi: the row's place among the non-pivotal (bit 31 clear) or among the pivotal rows (bit 31 set).
  *    sv[SV_PPF] = number of non-pivotal rows, or -1 when some row does not qualify. */
-SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint32_t *lds, const int Fl)
+SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint32_t *lds, const int Fl, dig_t *b0)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane();
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
@@ -287,6 +287,57 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
         if (cand) { const int at = bC + slip_popc64(mC & ((1ull << lane) - 1ull)); if (at < SLIP_PP_CAND) cl[at] = (uint32_t) t; }
     }
     slip_block_sync();
+    /* Class-B candidates (updated rows; their bounds have two bits of slack) keep a column from travelling as a package.  The
+     * worker has time now: compare each of them EXACTLY with the best class-S candidate at the level of the latest pivot it
+     * knows, rho[Fl-1] -- x rho[Fl-1] / rho[h] against a_best rho[Fl-1]; the common factor rho[k-1] / rho[Fl-1] that is
+     * still to come does not change the order.  A B candidate strictly on the far side can never be the pivot and leaves
+     * the list; if all of them do, the column is a candidates-only package after all. */
+    if (sv[SV_PP + 12] && any && sbest != ~0ull && Fl >= 1 && sv[SV_PP + 1] >= 2 && sv[SV_PP + 1] <= SLIP_PP_CAND && P.committer) {
+        const int ncand0 = sv[SV_PP + 1], wave = slip_wave(), nw = slip_nwaves();
+        const uint64_t av = kind == 0 ? sbest : ~sbest;
+        const uint32_t a0 = (uint32_t) av, a1 = (uint32_t)(av >> 32);
+        const int nd = a1 ? 2 : 1;
+        if (tid == 0) sv[SV_TMP3] = 0;                         /* B candidates that stay */
+        slip_block_sync();
+        for (int c = wave; c < ncand0; c += nw) {
+            const int t = (int) cl[c];
+            const int cls = (int)(f_inf[t] & 3u), r = (int) f_row[t];
+            if (cls != 3) continue;
+            int keep = 1;
+            const int h = P.xrow[r].h;
+            if (r != col && h >= 0 && h < Fl - 1) {
+                const int cmp = slip_cand_compare_out(&P, r, Fl - 1, h, a0, a1, nd, b0);
+                keep = kind == 0 ? !(cmp == 1) : !(cmp == -1);
+            } else if (r != col && h == Fl - 1) {
+                /* already at level Fl-1: its digits against a_best rho[Fl-1] -- left to the commit (rare) */
+                keep = 1;
+            }
+            if (lane == 0) { if (keep) sv[SV_TMP3] = 1; else cl[c] = 0xFFFFFFFFu; }
+        }
+        slip_block_sync();
+        if (!sv[SV_TMP3]) {
+            if (tid == 0) {
+                int m = 0;
+                for (int c = 0; c < ncand0; c++) if (cl[c] != 0xFFFFFFFFu) cl[m++] = cl[c];
+                sv[SV_PP + 1] = m; sv[SV_PP + 12] = 0;
+            }
+        } else if (tid == 0) {
+            /* some B candidate stays: the list is as the bounds made it (the marks are undone from the table) */
+            int m = 0;
+            for (int t = 0; t < nrows && m < SLIP_PP_CAND; t++) {
+                const uint32_t inf = f_inf[t];
+                const int cls = (int)(inf & 3u);
+                if (!cls) continue;
+                const uint32_t ubc = inf >> 2, lbc = ubc - (cls == 2 ? 1u : 2u);
+                int cand = kind == 0 ? lbc <= bestb : ubc >= bestb;
+                if (cand && cls == 2) { const uint64_t xv = (uint64_t) f_k0[t] | ((uint64_t) f_k1[t] << 32); cand = (kind == 0 ? xv : ~xv) == sbest; }
+                if (diagpref && (int) f_row[t] == col) cand = 1;
+                if (cand) cl[m++] = (uint32_t) t;
+            }
+            sv[SV_PP + 1] = m;
+        }
+        slip_block_sync();
+    }
     if (tid == 0) {
         sv[SV_PP] = any && sv[SV_PP + 1] >= 1 && sv[SV_PP + 1] <= SLIP_PP_CAND;
         sv[SV_PPF] = (want_full && !sv[SV_PPF]) ? sv[SV_TMP] : -1;
@@ -350,7 +401,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
                 if (!pp_fresh) {
                     Fn = slip_wait_frontier(st, lds, Fl + 1, k, 1);
                     if (Fn >= 0 && Fn <= Fl) {       /* nothing to do but wait: classify the rows and list the pivot candidates meanwhile */
-                        slip_prepass(P, k, tag, lds, Fl);
+                        slip_prepass(P, k, tag, lds, Fl, b0);
                         pp_fresh = 1;
 #ifdef SLIP_EMU_TRACE
                         if (tid == 0) fprintf(stderr, "worker: col %d prepass valid %d ncand %d nonS %d nrows %d full %d committer %d\n", k, (int) sv[SV_PP], (int) sv[SV_PP + 1], (int) sv[SV_PP + 12], (int) sv[SV_NROWS], (int) sv[SV_PPF], P.committer);
@@ -451,7 +502,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
                     if (!up_) { if (tid == 0) sv[SV_CUP] = slip_ld_i32(&st->committer_up); slip_block_sync(); }
                 }
                 if (sv[SV_CUP] && sv[SV_PKGVER] < 120 && k < (1 << 24) - 1) {
-                    slip_prepass(P, k, tag, lds, jn);               /* rows at positions >= jn travel with their values */
+                    slip_prepass(P, k, tag, lds, jn, b0);               /* rows at positions >= jn travel with their values */
                     if (sv[SV_PPF] >= 1 && sv[SV_PPF] <= SLIP_PKG_FULLMAX) {
                         if (tid == 0) { sv[SV_PKGF] = jn; sv[SV_PP] = 0; if (sv[SV_PKGVER]) slip_agent_add_u64(&st->c_retract, 1ull << 32); }
                         slip_export_full(P, k, lds, jn, jn);

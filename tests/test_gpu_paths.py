@@ -88,11 +88,18 @@ def test_gpu_stop_grow_relaunch():
 def test_gpu_two_handles_run_concurrently():
     """two factorisations on two streams at the same time (each launch has its own committer; a launch whose committer is
     not resident yet falls back to worker commits -- nothing waits for a workgroup that has not started)"""
-    import torch
+    import ctypes as C
     import slip_lu_amd as sl
     import slabfile
     cases = [_factor("rl5934", workers=96), _factor("fome12", workers=96)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    # two HIP streams from the runtime the library itself is linked against (no second runtime in this process)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    streams = []
+    for _ in range(2):
+        h = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(h)) == 0 and h.value
+        streams.append(h.value)
     errs = []
 
     def go(idx):
@@ -100,7 +107,7 @@ def test_gpu_two_handles_run_concurrently():
             entry, fix, f = cases[idx]
             for rep in range(3):
                 f.reset()
-                rc = f.run(entry["kmax"], stream=streams[idx].cuda_stream, check=False)
+                rc = f.run(entry["kmax"], stream=streams[idx], check=False)
                 assert rc == 0
                 assert slabfile.factor_digest(f.download()) == entry["digest"], (idx, rep)
         except Exception as e:                       # noqa: BLE001
@@ -112,4 +119,7 @@ def test_gpu_two_handles_run_concurrently():
         t.join()
     for _, _, f in cases:
         f.close()
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    for h in streams:
+        hip.hipStreamDestroy(h)
     assert not errs, errs
