@@ -21,7 +21,7 @@
 SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *lds, const int F0, const int Fl);
 SLIP_DEV void slip_export_full(const SlipParams &P, const int k, uint32_t *lds, const int F0, const int Fl);
 #ifndef SLIP_K1_NEAR
-#define SLIP_K1_NEAR 12                     /* a full package goes out when the frontier is within this many columns of the column */
+#define SLIP_K1_NEAR 4                      /* a full package goes out when the frontier is within this many columns of the column */
 #endif
 SLIP_DEV void slip_retract_package(const SlipParams &P, const int k, volatile int32_t *sv);
 

@@ -64,7 +64,7 @@ SlipCommitLayout slip_commit_layout(int n, int engine)
     L.lring = o; o += engine ? 3 * SLIP_LRING : 0;
     L.est_row = o; o += engine ? SLIP_ENG_ROWS : 0; L.est_vlo = o; o += engine ? SLIP_ENG_ROWS : 0;
     L.est_vhi = o; o += engine ? SLIP_ENG_ROWS : 0; L.est_meta = o; o += engine ? SLIP_ENG_ROWS : 0;
-    L.est_hash = o; o += engine ? 512 : 0;
+    L.est_hash = o; o += engine ? (n + 3) / 4 : 0;       /* the engine's row -> place map, one byte per row of the matrix */
     L.misc = o; o += 192;
     L.Ms = o; o += SLIP_CB_SLOTW;
     L.scr = o; o += 3 * SLIP_COMMIT_SCR;
@@ -225,7 +225,8 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
     uint32_t *ring_row = base + Ly.ring_row, *ring_disp = base + Ly.ring_disp, *ring_opos = base + Ly.ring_opos;
     uint32_t *pr_lo0 = base + Ly.pr_lo0, *pr_lo1 = base + Ly.pr_lo1, *pr_inv0 = base + Ly.pr_inv0, *pr_inv1 = base + Ly.pr_inv1, *pr_meta = base + Ly.pr_meta;
     uint32_t *ld_start = base + Ly.ld_start, *ld_cnt = base + Ly.ld_cnt, *ld_col = base + Ly.ld_col, *lring = base + Ly.lring;
-    uint32_t *est_row = base + Ly.est_row, *est_vlo = base + Ly.est_vlo, *est_vhi = base + Ly.est_vhi, *est_meta = base + Ly.est_meta, *est_hash = base + Ly.est_hash;
+    uint32_t *est_row = base + Ly.est_row, *est_vlo = base + Ly.est_vlo, *est_vhi = base + Ly.est_vhi, *est_meta = base + Ly.est_meta;
+    uint8_t *slotm = (uint8_t *)(base + Ly.est_hash);              /* engine: place + 1 of a row in the column being committed, 0 = not in it */
     uint32_t *misc = base + Ly.misc;
     uint32_t *ck_pos = misc, *hver = misc + 64;                     /* candidate positions; the versions of the batch's packages as the poll saw them */
     unsigned long long *eacc = (unsigned long long *)(misc + 128);  /* the engine's algorithmic counters (8 x 64 bit) */
@@ -254,17 +255,8 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         pr_lo0[s_] = (uint32_t) pv.lo; pr_lo1[s_] = (uint32_t)(pv.lo >> 32); pr_inv0[s_] = (uint32_t) pv.inv64; pr_inv1[s_] = (uint32_t)(pv.inv64 >> 32);
         pr_meta[s_] = (uint32_t)(pv.ctz & 0xFF) | (pv.len < 0 ? 0x100u : 0u) | (small ? 0x200u : 0u) | ((uint32_t)(small ? pv.bits : 0) << 16);
     };
-    auto hslot = [&](uint32_t row) -> uint32_t { return (row * 2654435761u) >> 23; };        /* 9 bits */
-    auto est_lookup = [&](uint32_t row) -> int {
-        uint32_t s_ = hslot(row);
-        for (int p_ = 0; p_ < 512; p_++) { const uint32_t e = est_hash[s_]; if (e == 0u) return -1; if ((e >> 8) == row + 1u) return (int)(e & 255u); s_ = (s_ + 1u) & 511u; }
-        return -1;
-    };
-    auto est_insert = [&](uint32_t row, int idx) {
-        uint32_t s_ = hslot(row); const uint32_t v = ((row + 1u) << 8) | (uint32_t) idx;
-        for (int p_ = 0; p_ < 512; p_++) { if (slip_atomic_cas_u32(&est_hash[s_], 0u, v) == 0u) break; s_ = (s_ + 1u) & 511u; }
-    };
-
+    auto est_lookup = [&](uint32_t row) -> int { return (int) slotm[row] - 1; };
+    auto est_insert = [&](uint32_t row, int idx) { slotm[row] = (uint8_t)(idx + 1); };
     if (tid == 0) {
         int pr_; const int F0 = slip_ld_frontier(st, &pr_);
         sv[C_K] = F0; sv[C_HAVE] = 0; sv[C_RING0] = F0; sv[C_REJ] = -1; sv[C_REJV] = 0; sv[C_LW] = 0; sv[C_PR0] = F0;
@@ -272,7 +264,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         if (F0 >= 1) { const SlipPiv pv = slip_ld_piv(&P.piv[F0 - 1]); pring_put(F0 - 1, pv); sv[C_PR0] = F0 - 1; }
     }
     for (int w = tid; w < SLIP_CB_RING; w += T) { ld_col[w] = 0xFFFFFFFFu; ld_cnt[w] = 0xFFFFFFFFu; }
-    if (mirror) for (int i = tid; i < P.n; i += T) pinvm[i] = (uint16_t) slip_ld_i32(&P.pinv[i]);
+    if (mirror) for (int i = tid; i < P.n; i += T) { pinvm[i] = (uint16_t) slip_ld_i32(&P.pinv[i]); slotm[i] = 0; }
     slip_block_sync();
     if (tid == 0) slip_agent_store_i32(&st->committer_up, 1);       /* from now on packages are answered */
 #ifdef SLIP_PROFILE_COMMIT
@@ -617,7 +609,6 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     uint32_t lsrc[4] = {BIG, BIG, BIG, BIG};
                     if (!reject) {
                         /* E1: the state arrays and the row -> place table */
-                        for (int w = lane; w < 512; w += SLIP_WAVE) est_hash[w] = 0u;
                         for (int q = 0; q < 2; q++) {
                             const int t = lane + 64 * q;
                             if (t < nfull) { est_row[t] = prow[t]; est_vlo[t] = pvlo[t]; est_vhi[t] = pvhi[t]; est_meta[t] = pmeta[t] & 0xBFFFFFFFu; }
@@ -712,7 +703,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                             const int fresh = has && idx < 0;
                             const uint64_t fm = slip_ballot(fresh);
                             const int nf = slip_popc64(fm);
-                            if (nst + nf > SLIP_ENG_ROWS) { reject = 2; break; }
+                            if (nst + nf > SLIP_ENG_ROWS - 1) { reject = 2; break; }       /* places travel as bytes: 255 rows */
                             if (fresh) {
                                 /* structural discovery (what the reference's DFS does): a row the column did not hold yet */
                                 idx = nst + slip_popc64(fm & ((1ull << lane) - 1ull));
@@ -769,7 +760,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                             }
                             if (slip_ballot(ovf)) { reject = 2; break; }
                             slip_wave_sync_lds();
-                            for (int q = nst_old >> 6; q < 4 && 64 * q < nst; q++) {       /* a filled-in row may itself have become pivotal meanwhile: a later source */
+                            if (nf) for (int q = nst_old >> 6; q < 4 && 64 * q < nst; q++) {       /* a filled-in row may itself have become pivotal meanwhile: a later source */
                                 const int t = lane + 64 * q;
                                 if (t >= nst_old && t < nst) { const uint32_t p = (uint32_t) pinvm[est_row[t]]; lsrc[q] = (int) p < j ? p : BIG; }
                             }
@@ -890,6 +881,9 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                             }
                         }
                     }
+                    /* the row -> place map is the next column's: leave it empty */
+                    slip_wave_sync_lds();
+                    for (int q = 0; q < 4 && 64 * q < nst; q++) { const int t = lane + 64 * q; if (t < nst) slotm[est_row[t]] = 0; }
                     SLIP_CT(19);
                     if (lane == 0) sv[C_LW] = (int32_t) lw;                                                   /* (columns fetched from memory stay in the ring also when this package goes back) */
                     if (reject && lane == 0) slip_st_u32(mbx + SLIP_PKG_OUT + 1, (uint32_t) reject);      /* why it goes back (1: try again later) */
