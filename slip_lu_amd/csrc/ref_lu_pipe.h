@@ -1079,21 +1079,22 @@ SLIP_DEV int slip_submul_wave(const SlipParams &P, int i, int j, int64_t m, dig_
 
 /* kind 1: IPGE updates of source (j, jn), items = (m - m0, i) pairs; kind 2: history rows of column k (division by rho[h]);
  * kind 4: x * rho[k-1]; kind 5: back-substitution updates (m - m0, i) of source j */
-SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, int64_t m0, const uint32_t *items, int t,
+SLIP_DEV int slip_run_item(const SlipParams &P, int kind, int j, int jn, int k, int64_t m0, uint32_t ia, uint32_t ib,
                            dig_t *b0, dig_t *b1, dig_t *b2)
 {
-    if (kind == 1) return slip_ipge_wave(P, (int) items[2 * t + 1], j, jn, m0 + (int64_t) items[2 * t], b0, b1, b2);
-    if (kind == 5) return slip_submul_wave(P, (int) items[2 * t + 1], j, m0 + (int64_t) items[2 * t], b0, b1, b2);
-    const int r = (int) items[t];
+    if (kind == 1) return slip_ipge_wave(P, (int) ib, j, jn, m0 + (int64_t) ia, b0, b1, b2);
+    if (kind == 5) return slip_submul_wave(P, (int) ib, j, m0 + (int64_t) ia, b0, b1, b2);
+    const int r = (int) ia;
     if (kind == 4) return slip_history_wave(P, r, k - 1, -1, b0, b1, b2, SLIP_KEEP_H);      /* x * rho[k-1] */
     { const int h = P.xrow[r].h; return slip_history_wave(P, r, k - 1, h, b0, b1, b2, k - 1); }   /* now at level k-1 */
 }
 
-/* ---- out-of-line entry points (one copy each; the parameters are the workgroup's LDS copy) ---- */
-SLIP_DEVN int slip_run_item_out(const SlipParams *Pg, int kind, int j, int jn, int k, int64_t m0, const uint32_t *items, int t,
+/* ---- out-of-line entry points (one copy each; the parameters are the workgroup's LDS copy; items travel by value:
+ * (m - m0, i) for kinds 1 and 5, (row, -) otherwise) ---- */
+SLIP_DEVN int slip_run_item_out(const SlipParams *Pg, int kind, int j, int jn, int k, int64_t m0, uint32_t ia, uint32_t ib,
                                 dig_t *b0, dig_t *b1, dig_t *b2)
 {
-    return slip_run_item(*Pg, kind, j, jn, k, m0, items, t, b0, b1, b2);
+    return slip_run_item(*Pg, kind, j, jn, k, m0, ia, ib, b0, b1, b2);
 }
 SLIP_DEVN int slip_history_wave_out(const SlipParams *Pg, int r, int pm, int pd, dig_t *b0, dig_t *b1, dig_t *b2)
 {
@@ -1163,12 +1164,12 @@ SLIP_DEV int slip_farm_items(const SlipParams &P, uint32_t *jb, int kind, int j,
         if (slip_lane() == 0) t = slip_agent_add_i32((int32_t *)(jb + 16), 1);
         t = (int) slip_bcast0_u32((uint32_t) t);
         if (t >= nq) break;
-        uint32_t it[2];                          /* kind 1: (entry, row) pairs; kind 2: rows */
+        uint32_t it0, it1;                       /* kind 1: (entry, row) pairs; kind 2: rows */
         if (kind == 1) {
-            if (wl) { it[0] = wl[2 * t]; it[1] = wl[2 * t + 1]; }
-            else { it[0] = slip_ld_u32(jb + 32 + 2 * t); it[1] = slip_ld_u32(jb + 32 + 2 * t + 1); }
-        } else { it[0] = wl ? wl[t] : slip_ld_u32(jb + 32 + t); it[1] = 0u; }
-        const int e = slip_run_item_out(&P, kind, j, jn, k, m0, it, 0, b0, b1, b2);
+            if (wl) { it0 = wl[2 * t]; it1 = wl[2 * t + 1]; }
+            else { it0 = slip_ld_u32(jb + 32 + 2 * t); it1 = slip_ld_u32(jb + 32 + 2 * t + 1); }
+        } else { it0 = wl ? wl[t] : slip_ld_u32(jb + 32 + t); it1 = 0u; }
+        const int e = slip_run_item_out(&P, kind, j, jn, k, m0, it0, it1, b0, b1, b2);
         if (e) err = e;
         cnt++;
     }
@@ -1282,7 +1283,7 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
                 if (wave == nw - 1 && lane == 0 && (slip_ld_i64(&P.st->stop) >> 8) < (int64_t) sv[SV_K]) sv[SV_ABORT] = 1;
                 if ((int) slip_bcast0_u32((uint32_t) sv[SV_ABORT])) break;      /* one lane's view for the whole wave */
             }
-            const int e = slip_run_item_out(&P, kind, j, jn, k, m0, wl, t, b0, b1, b2);
+            const int e = slip_run_item_out(&P, kind, j, jn, k, m0, (kind == 1 || kind == 5) ? wl[2 * t] : wl[t], (kind == 1 || kind == 5) ? wl[2 * t + 1] : 0u, b0, b1, b2);
             if (e && lane == 0) sv[SV_ERR] = e;
         }
     slip_block_sync();

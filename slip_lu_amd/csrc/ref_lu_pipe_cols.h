@@ -1265,7 +1265,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                     slip_vm_drain();
                 }
                 for (int t = 0; t < ncB; t += nw) {
-                    const int e = slip_run_item_out(&P, 2, 0, 0, k, 0, wlB, t, b0, b1, b2);
+                    const int e = slip_run_item_out(&P, 2, 0, 0, k, 0, wlB[t], 0u, b0, b1, b2);
                     if (e && lane == 0) sv[SV_ERR] = e;
                 }
                 slip_wave_sync();
@@ -1304,7 +1304,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                     slip_vm_drain();
                 }
                 for (int t = wave; t < ncB; t += nw) {
-                    const int e = slip_run_item_out(&P, 2, 0, 0, k, 0, wlB, t, b0, b1, b2);
+                    const int e = slip_run_item_out(&P, 2, 0, 0, k, 0, wlB[t], 0u, b0, b1, b2);
                     if (e && lane == 0) sv[SV_ERR] = e;
                 }
                 slip_wave_sync();

@@ -64,7 +64,7 @@ SlipCommitLayout slip_commit_layout(int n, int engine)
     L.lring = o; o += engine ? 3 * SLIP_LRING : 0;
     L.est_row = o; o += engine ? SLIP_ENG_ROWS : 0; L.est_vlo = o; o += engine ? SLIP_ENG_ROWS : 0;
     L.est_vhi = o; o += engine ? SLIP_ENG_ROWS : 0; L.est_meta = o; o += engine ? SLIP_ENG_ROWS : 0;
-    L.est_hash = o; o += engine ? (n + 3) / 4 : 0;       /* the engine's row -> place map, one byte per row of the matrix */
+    L.est_hash = o; o += engine ? 2 * ((n + 7) / 8) : 0;       /* the engine's row -> place map, one byte per row of the matrix */
     L.misc = o; o += 192;
     L.Ms = o; o += SLIP_CB_SLOTW;
     L.scr = o; o += 3 * SLIP_COMMIT_SCR;
@@ -617,7 +617,8 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                         for (int q = 0; q < 2; q++) { const int t = lane + 64 * q; if (t < nfull) est_insert(prow[t], t); }
                         slip_wave_sync_lds();
                         /* E2: the rows that have become pivotal since the export are the sources still to be applied */
-                        for (int q = 0; q < 4 && 64 * q < nst; q++) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {                   /* (constant indices: the array stays in registers) */
                             const int t = lane + 64 * q;
                             if (t < nst) { const uint32_t p = (uint32_t) pinvm[est_row[t]]; if ((int) p < j) lsrc[q] = p; }
                         }
@@ -632,11 +633,11 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                         if (cu == BIG) break;
                         const int c = (int) cu;
                         int oq = -1;
-                        for (int q = 0; q < 4; q++) if (lsrc[q] == cu) oq = q;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) if (lsrc[q] == cu) { oq = q; lsrc[q] = BIG; }
                         const uint64_t ob = slip_ballot(oq >= 0);
                         const int ol = slip_ctz64(ob);
                         const int jt = ol + 64 * (int) slip_readlane((uint32_t)(oq < 0 ? 0 : oq), ol);
-                        if (oq >= 0) lsrc[oq] = BIG;
                         const int cs = c & (SLIP_CB_RING - 1);
                         if (c - 1 < pr0) { reject = 1; break; }
                         if (ld_col[cs] != (uint32_t) c || (int32_t) ld_cnt[cs] < 0 || (uint32_t)(lw - ld_start[cs]) > (uint32_t) SLIP_LRING) {
@@ -760,7 +761,9 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                             }
                             if (slip_ballot(ovf)) { reject = 2; break; }
                             slip_wave_sync_lds();
-                            if (nf) for (int q = nst_old >> 6; q < 4 && 64 * q < nst; q++) {       /* a filled-in row may itself have become pivotal meanwhile: a later source */
+                            if (nf)
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {       /* a filled-in row may itself have become pivotal meanwhile: a later source */
                                 const int t = lane + 64 * q;
                                 if (t >= nst_old && t < nst) { const uint32_t p = (uint32_t) pinvm[est_row[t]]; lsrc[q] = (int) p < j ? p : BIG; }
                             }
