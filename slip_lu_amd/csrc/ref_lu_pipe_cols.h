@@ -1111,6 +1111,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 if (lane == 0) {
                     slip_st_frontier(st, k + 1, e_pivrow);
 #ifdef SLIP_PROFILING
+                    P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 2] = (int32_t) slip_realtime();      /* time line 2: committed (by its worker) */
                     if (t_last_) prof_[18] += slip_clock() - t_last_;
                     {
                         int32_t *tr = P.dbg + 8 * (int64_t) k; const unsigned long long nowc = slip_clock();
@@ -1918,6 +1919,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             slip_vm_drain();
             slip_st_frontier(st, k + 1, pivrow);
 #ifdef SLIP_PROFILING
+            P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 2] = (int32_t) slip_realtime();              /* time line 2: committed (by its worker) */
             /* slot 18: from the moment this worker learnt that column k-1 was committed to its own commit */
             if (t_last_) prof_[18] += slip_clock() - t_last_;
             {
