@@ -67,7 +67,8 @@ typedef struct { int64_t off; int32_t len, bits; } SlipEnt;       /* off in 64-b
 typedef struct {
     int64_t off; int32_t len, bits;          /* limbs in the L slab */
     uint64_t lo; int32_t ctz, invlen;        /* low limb; trailing zero bits; cached inverse digits */
-    uint64_t inv64, pad;                     /* inverse of the odd part modulo 2^64 (one-limb pivots) */
+    uint64_t inv64, pad;                     /* inverse of the odd part modulo 2^64 (one-limb pivots); pad: how many divisions by this
+                                              * pivot found its cached inverse too short (slip_div_piv_reg decides on it) */
 } SlipPiv;
 
 /* mutable across launches; the words other workers poll sit in 128-byte lines of their own */
@@ -350,6 +351,7 @@ SLIP_DEV void slip_st_piv(SlipPiv *p, const SlipPiv &v)
     slip_st_u64(w + 2, v.lo);
     slip_st_u64(w + 3, (uint64_t)(uint32_t) v.ctz | ((uint64_t)(uint32_t) v.invlen << 32));
     slip_st_u64(w + 4, v.inv64);
+    slip_st_u64(w + 5, 0ull);
 }
 SLIP_DEV SlipEnt slip_ld_ent(const SlipEnt *p)
 {
@@ -524,16 +526,9 @@ SLIP_DEV int slip_store_x(const SlipParams &P, int i, const dig_t *q, int W, int
 
 /* ---- register-resident versions (operands of at most 64*D digits; wave_bigint_reg.h) ---- */
 
-/* cached inverse of pivot p's odd part to `want` digits, register Newton; b0: scratch for wide shifts */
-template <int D> SLIP_DEV int slip_ensure_inv_reg(const SlipParams &P, int p, int want, dig_t *b0)
+/* the odd part of pivot pv (its digits shifted down by its trailing zero bits), low 64*D digits; b0: scratch for wide shifts */
+template <int D> SLIP_DEV WR<D> slip_piv_odd_reg(const SlipParams &P, const SlipPiv &pv, dig_t *b0)
 {
-    int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(&P.piv[p]));
-    if (have >= want) return 0;
-    if (want > P.invcap) return 1;
-    int target = 2 * have > want ? 2 * have : want;
-    if (target > P.invcap) target = P.invcap;
-    if (target > 64 * D) target = 64 * D;
-    const SlipPiv pv = slip_ld_piv(&P.piv[p]);
     const int ld = slip_abs(pv.len);
     WR<D> dodd;
     if (ld > 64 * D) {               /* the shift must see the digits above the register window */
@@ -546,12 +541,58 @@ template <int D> SLIP_DEV int slip_ensure_inv_reg(const SlipParams &P, int p, in
             dodd.d[q] = sb ? ((lo >> sb) | (hi << (32 - sb))) : lo;
         }
     } else dodd = wr_shr<D>(wr_load_s<D>(slip_piv_digits(P, pv), ld), pv.ctz, b0);
+    return dodd;
+}
+
+/* cached inverse of pivot p's odd part to `want` digits, register Newton; b0: scratch for wide shifts */
+template <int D> SLIP_DEV int slip_ensure_inv_reg(const SlipParams &P, int p, int want, dig_t *b0)
+{
+    int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(&P.piv[p]));
+    if (have >= want) return 0;
+    if (want > P.invcap) return 1;
+    int target = 2 * have > want ? 2 * have : want;
+    if (target > P.invcap) target = P.invcap;
+    if (target > 64 * D) target = 64 * D;
+    const SlipPiv pv = slip_ld_piv(&P.piv[p]);
+    const WR<D> dodd = slip_piv_odd_reg<D>(P, pv, b0);
     dig_t *inv = P.invd + (int64_t) p * P.invcap;
     WR<D> V = wr_inv_extend<D>(wr_load_s<D>(inv, have), have, target, dodd);
     wr_store_s<D>(inv, V, target);
     slip_vm_drain();
     if (slip_lane() == 0) slip_agent_max_i32(&P.piv[p].invlen, target);
     slip_wave_sync();
+    return 0;
+}
+
+/* Y / rho[pd] exactly, Y already shifted down by the divisor's trailing zero bits and cut to the W digits of the quotient;
+ * for divisors that belong to ONE row's history (the rho[h] of slip_REF_triangular_solve.c:147,226,255), not to a source
+ * every row of the update divides by.  The cached 2-adic inverse is used when it is long enough.  Otherwise the first
+ * SLIP_INV_DEMAND divisions by this pivot go digit by digit (wr_div_hensel: half the cost of extending the inverse for ONE
+ * use), and a pivot that is asked for again gets its inverse extended.  The count lives in the pivot's record; a stale read
+ * changes which way the same quotient is computed, nothing else.
+ * Measured (MI355X, kernel ms, never / first two / always digit by digit): C4 window 3.83 / 3.72-3.84 / 3.93, NSR8K 507 /
+ * 512 / 526, model6 628 / 627-636 / 644, d18512 550 / 550 / 550: the inverses ARE reused -- the rows of a heavy column share
+ * few history levels -- so the Newton extension is paid once per (pivot, width) and a product against the cached inverse
+ * (one wr_mul) beats W dependent steps every time after that.  One digit-by-digit division per pivot is the default. */
+#ifndef SLIP_INV_DEMAND
+#define SLIP_INV_DEMAND 1
+#endif
+template <int D> SLIP_DEV int slip_div_piv_reg(const SlipParams &P, WR<D> &Y, int W, int pd, const SlipPiv &d, dig_t *b0)
+{
+    const int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(&P.piv[pd]));
+    if (have < W) {
+        const uint32_t asked = slip_bcast0_u32(slip_ld_u32((const uint32_t *) &P.piv[pd].pad));
+        if (asked < (uint32_t) SLIP_INV_DEMAND) {
+            if (slip_lane() == 0) (void) slip_agent_add_i32((int32_t *) &P.piv[pd].pad, 1)       /* (result unused: the no-return form) */;
+            const WR<D> dodd = slip_piv_odd_reg<D>(P, d, b0);
+            Y = wr_div_hensel<D>(Y, W, dodd);
+            return 0;
+        }
+        const int e = slip_ensure_inv_reg<D>(P, pd, W, b0);
+        if (e) return e;
+    }
+    const WR<D> I = wr_load_s<D>(P.invd + (int64_t) pd * P.invcap, W);
+    Y = wr_mask<D>(wr_mul<D>(I, W, Y), W);
     return 0;
 }
 
@@ -596,12 +637,11 @@ template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, 
     if (pd >= 0) {
         const SlipPiv d = slip_ld_piv(&P.piv[pd]);
         const int W = (xr.bits + m.bits - d.bits + 1 + 31) >> 5;
-        { const int e = slip_ensure_inv_reg<D>(P, pd, W, b0); if (e) return e; }
+        if (W > P.invcap) return 1;
         WR<D> X = wr_load_g<D>(P.xd + (int64_t) r * P.xcap, lx), M = wr_load_s<D>(slip_piv_digits(P, m), lm);
         WR<D> Y = lx <= lm ? wr_mul<D>(X, lx < 64 * D ? lx : 64 * D, M) : wr_mul<D>(M, lm < 64 * D ? lm : 64 * D, X);
         Y = wr_mask<D>(wr_shr<D>(Y, d.ctz, b0), W);
-        WR<D> I = wr_load_s<D>(P.invd + (int64_t) pd * P.invcap, W);
-        Y = wr_mask<D>(wr_mul<D>(I, W, Y), W);
+        { const int e = slip_div_piv_reg<D>(P, Y, W, pd, d, b0); if (e) return e; }
         return slip_store_x_reg<D>(P, r, Y, sign * slip_sgn(d.len), xr.h, xr.tag);
     }
     WR<D> X = wr_load_g<D>(P.xd + (int64_t) r * P.xcap, lx), M = wr_load_s<D>(slip_piv_digits(P, m), lm);
@@ -636,13 +676,12 @@ template <int D> SLIP_DEV int slip_cand_compare_reg(const SlipParams &P, int r, 
     const int lm = slip_abs(m.len);
     const SlipPiv d = slip_ld_piv(&P.piv[pd]);
     const int W = (xr.bits + m.bits - d.bits + 1 + 31) >> 5;
-    { const int e = slip_ensure_inv_reg<D>(P, pd, W, b0); if (e) return 2; }
+    if (W > P.invcap) return 2;
     const WR<D> M = wr_load_s<D>(slip_piv_digits(P, m), lm);
     WR<D> X = wr_load_g<D>(P.xd + (int64_t) r * P.xcap, lx);
     WR<D> Y = lx <= lm ? wr_mul<D>(X, lx < 64 * D ? lx : 64 * D, M) : wr_mul<D>(M, lm < 64 * D ? lm : 64 * D, X);
     Y = wr_mask<D>(wr_shr<D>(Y, d.ctz, b0), W);
-    const WR<D> I = wr_load_s<D>(P.invd + (int64_t) pd * P.invcap, W);
-    Y = wr_mask<D>(wr_mul<D>(I, W, Y), W);
+    if (slip_div_piv_reg<D>(P, Y, W, pd, d, b0)) return 2;
     WR<D> A;
     if (nd == 1) A = wr_mul_digit<D>(a0, M);
     else {
@@ -743,7 +782,7 @@ template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int
     const int lx = slip_abs(xi.len);
     SlipPiv Dv = slip_piv_none();
     if (has_d) Dv = slip_ld_piv(&P.piv[jn - 1]);
-    if (hdiv) { const int e = slip_ensure_inv_reg<D>(P, xi.h, W1, b0); if (e) return e; }
+    if (hdiv && W1 > P.invcap) return 1;
     if (has_d) { const int e = slip_ensure_inv_reg<D>(P, jn - 1, W, b0); if (e) return e; }
     const int CAP = 64 * D;
     const int lr = slip_abs(R.len) < W1 ? slip_abs(R.len) : W1;
@@ -764,8 +803,7 @@ template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int
             if (hdiv) {
                 const SlipPiv H = slip_ld_piv(&P.piv[xi.h]);
                 Y = wr_mask<D>(wr_shr<D>(Y, H.ctz, b0), W1);
-                WR<D> IH = wr_load_s<D>(P.invd + (int64_t) xi.h * P.invcap, W1);
-                Y = wr_mul<D>(IH, W1, Y);
+                { const int e = slip_div_piv_reg<D>(P, Y, W1, xi.h, H, b0); if (e) return e; }
                 s1 *= slip_sgn(H.len);
             }
             Y = wr_mask<D>(Y, W1);

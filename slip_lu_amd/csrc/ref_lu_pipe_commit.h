@@ -1004,6 +1004,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     case 8: a8 = (uint64_t *) &P.Lo[j + 1]; v8 = (uint64_t) pb[18] | ((uint64_t) pb[19] << 32); break;
                     case 9: a8 = (uint64_t *)(mbx + SLIP_PKG_OUT + 6); v8 = (uint64_t) poff; break;
                     case 10: a8 = (uint64_t *)(mbx + SLIP_PKG_OUT + 8); v8 = (uint64_t) pb[10] | ((uint64_t) pb[11] << 32); break;
+                    case 11: a8 = pw + 5; v8 = 0ull; break;                   /* (nobody has divided by this pivot yet) */
                     default: break;
                 }
                 if (a8) slip_st_u64(a8, v8);

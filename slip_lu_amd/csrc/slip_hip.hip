@@ -33,7 +33,7 @@
 /* kernels                                                             */
 /* ------------------------------------------------------------------ */
 /* register-resident primitives (wave_bigint_reg.h) for the unit tests: op 10 product, 11 add, 12 sub,
- * 13 inverse of odd a, 14 a >> lb (lb = shift in bits); all modulo B^W, W <= 256 */
+ * 13 inverse of odd a, 14 a >> lb (lb = shift in bits), 15 a / b for odd b (Hensel); all modulo B^W, W <= 256 */
 template <int D> SLIP_DEV void slip_reg_op_test_d(int op, const uint32_t *A, int la, const uint32_t *B, int lb, int W,
                                                    uint32_t *O, uint32_t *scratch)
 {
@@ -44,6 +44,7 @@ template <int D> SLIP_DEV void slip_reg_op_test_d(int op, const uint32_t *A, int
         WR<D> b = wr_load<D>(B, lb < W ? lb : W);
         const int ea = la < W ? la : W, eb = lb < W ? lb : W;
         if (op == 10) r = ea <= eb ? wr_mul<D>(a, ea, b) : wr_mul<D>(b, eb, a);
+        else if (op == 15) r = wr_div_hensel<D>(a, W, b);
         else r = wr_addsub<D>(a, b, op == 12);
     }
     wr_store<D>(O, r, W);
@@ -266,6 +267,14 @@ slip_wave_bench_kernel(int op, int la, int lb, int W, int iters, int out_in_lds,
             else if (W <= 128) { WR<2> x = wr_load<2>(A, ea), y = wr_load<2>(B, lb < W ? lb : W); wr_store<2>(O, wr_mul<2>(x, ea, y), W); }
             else if (W <= 192) { WR<3> x = wr_load<3>(A, ea), y = wr_load<3>(B, lb < W ? lb : W); wr_store<3>(O, wr_mul<3>(x, ea, y), W); }
             else { WR<4> x = wr_load<4>(A, ea), y = wr_load<4>(B, lb < W ? lb : W); wr_store<4>(O, wr_mul<4>(x, ea, y), W); }
+        }
+        else if (op == 7 || op == 8) {         /* exact division of a W-digit number: 7 Hensel, 8 Newton inverse to W digits + product */
+            const int ea = la < W ? la : W, eb = lb < W ? lb : W;
+#define SLIP_BENCH_DIV(DD) do { WR<DD> x = wr_load<DD>(A, ea), y = wr_load<DD>(B, eb); if (slip_lane() == 0) y.d[0] |= 1u; \
+                if (op == 7) wr_store<DD>(O, wr_div_hensel<DD>(x, W, y), W); \
+                else { WR<DD> v = wr_inv_extend<DD>(wr_zero<DD>(), 0, W, y); wr_store<DD>(O, wr_mask<DD>(wr_mul<DD>(v, W, x), W), W); } } while (0)
+            if (W <= 64) SLIP_BENCH_DIV(1); else if (W <= 128) SLIP_BENCH_DIV(2); else if (W <= 192) SLIP_BENCH_DIV(3); else SLIP_BENCH_DIV(4);
+#undef SLIP_BENCH_DIV
         }
     }
     unsigned long long t1 = clock64();

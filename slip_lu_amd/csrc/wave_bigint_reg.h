@@ -263,4 +263,50 @@ template <int D> SLIP_DEV WR<D> wr_inv_extend(WR<D> V, int have, int want, const
     return V;
 }
 
+/* Exact division without an inverse (Hensel, digit-serial): Q with Q * Dodd = T (mod B^W), Dodd odd, W <= 64*D.
+ * The quotient digits come out one per step: column i of the running sum  sum_{i' < i} q_i' * Dodd * B^i'  is complete
+ * when step i starts, so q_i = (t_i - column_i) * d0^{-1} mod B with d0^{-1} mod B a five-instruction scalar Newton; then
+ * every lane adds q_i * d_{c-i} into its column (the same wave-wide shift register as wr_mul).  The carry from column to
+ * column travels through the scalar unit (three v_readlane, a dozen s_ instructions per step), so nothing is normalised
+ * and no 2-adic inverse of W digits is ever formed: 2.5 product-equivalents against the 3+ of Newton + product, with a
+ * tenth of the fixed costs (no wr_normalise, no masks).  Used for divisors nobody else divides by (the rho[h] of a row's
+ * history: mpz_divexact at slip_REF_triangular_solve.c:147,226,255); sources' rho[j-1] keep their cached inverses. */
+template <int D> SLIP_DEV WR<D> wr_div_hensel(const WR<D> &T, int W, const WR<D> &Dodd)
+{
+    const uint32_t d0 = slip_readlane(Dodd.d[0], 0);
+    uint32_t inv = d0;                                   /* d0 * d0 = 1 mod 8 */
+    inv *= 2u - d0 * inv; inv *= 2u - d0 * inv; inv *= 2u - d0 * inv; inv *= 2u - d0 * inv;
+    uint64_t acc[D];
+    uint32_t hi[D], Ds[D];
+    WR<D> Q;
+#pragma unroll
+    for (int r = 0; r < D; r++) { acc[r] = 0; hi[r] = 0; Ds[r] = Dodd.d[r]; Q.d[r] = 0; }
+    uint32_t c0 = 0, c1 = 0;                             /* the carry into the column of the current step (wave-uniform) */
+#pragma unroll
+    for (int ia = 0; ia < D; ia++) {
+        int steps = W - 64 * ia;
+        if (steps > 64) steps = 64;
+        for (int il = 0; il < steps; il++) {
+            /* column i = what the earlier digits left there + the carry; q_i makes its low word t_i */
+            const uint32_t s0 = slip_readlane((uint32_t) acc[ia], il), t = slip_readlane(T.d[ia], il);
+            const uint32_t q = slip_uniform((t - (s0 + c0)) * inv);
+            Q.d[ia] = slip_writelane(Q.d[ia], q, il);
+            /* column c >= i takes q_i * d[c - i] (lane l of chunk r holds d[64r + l - i] at step i, as in wr_mul) */
+#pragma unroll
+            for (int r = ia; r < D; r++) slip_mac96(acc[r], hi[r], q, Ds[r]);
+            /* lane i now holds column i without the carry that came in: low word + c0 = t_i (mod B), so the carry out of the
+             * low word is 1 exactly when t_i < c0; the upper words go on to column i + 1 */
+            const uint32_t m1 = slip_readlane((uint32_t)(acc[ia] >> 32), il), m2 = slip_readlane(hi[ia], il);
+            slip_carry_step(m1, c1, t, c0, m2, c0, c1);
+#pragma unroll
+            for (int r = D - 1; r >= ia; r--) {
+                if (r > ia) Ds[r] = slip_dpp_shr1_in(Ds[r], slip_readlane(Ds[r - 1], 63));
+                else Ds[r] = slip_dpp_shr1_zero(Ds[r]);
+            }
+        }
+    }
+    slip_valu_settle();
+    return Q;
+}
+
 #endif /* SLIP_WAVE_BIGINT_REG_H */

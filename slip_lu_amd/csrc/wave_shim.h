@@ -44,6 +44,16 @@ static inline uint32_t slip_emu_shl1(const uint64_t *o, uint32_t fill) { int l =
 #define slip_dpp_shl1(v, fill) slip_emu_shl1(emu::collective((uint64_t)(v), __LINE__), (fill))
 #define slip_readlane(v, lane) ((uint32_t) emu::shfl((uint64_t)(v), (lane), __LINE__))
 #define slip_dpp_shr1_in(v, in) slip_dpp_shr1((v), (in))
+/* a value the caller knows to be wave-uniform, kept in the scalar unit (no-op in the emulation) */
+#define slip_uniform(v) ((uint32_t)(v))
+/* Hensel carry step on wave-uniform words: (n1:n0) = m1 + c1 + (t < c0) + (m2 << 32) */
+static inline void slip_carry_step(uint32_t m1, uint32_t c1, uint32_t t, uint32_t c0, uint32_t m2, uint32_t &n0, uint32_t &n1)
+{
+    const uint64_t cn = (uint64_t) m1 + c1 + (t < c0 ? 1u : 0u) + ((uint64_t) m2 << 32);
+    n0 = (uint32_t) cn; n1 = (uint32_t)(cn >> 32);
+}
+/* the wave-uniform value s into lane `l` of v */
+#define slip_writelane(v, s, l) (((emu::tid() & 63) == (l)) ? (uint32_t)(s) : (uint32_t)(v))
 #define slip_dpp_shr1_zero(v) slip_dpp_shr1((v), 0u)
 static inline void slip_valu_settle(void) {}
 /* value of lane 0 in every lane (all lanes active) */
@@ -155,6 +165,20 @@ SLIP_DEV uint32_t slip_dpp_shl1(uint32_t v, uint32_t fill)
     return (uint32_t) __builtin_amdgcn_update_dpp((int) fill, (int) v, 0x130, 0xF, 0xF, false);
 }
 SLIP_DEV uint32_t slip_readlane(uint32_t v, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) v, lane); }
+/* a value the caller knows to be wave-uniform, kept in the scalar unit */
+SLIP_DEV uint32_t slip_uniform(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+/* Hensel carry step on wave-uniform words, in the scalar unit: (n1:n0) = m1 + c1 + (t < c0) + (m2 << 32).  Written out:
+ * the compiler selects the vector unit's add-with-carry for this (and then moves the whole quotient chain there) */
+SLIP_DEV void slip_carry_step(uint32_t m1, uint32_t c1, uint32_t t, uint32_t c0, uint32_t m2, uint32_t &n0, uint32_t &n1)
+{
+    /* (readfirstlane: an "s" operand the register allocator had put into a VGPR is emitted as such) */
+    m1 = slip_uniform(m1); c1 = slip_uniform(c1); t = slip_uniform(t); c0 = slip_uniform(c0); m2 = slip_uniform(m2);
+    asm("s_cmp_lt_u32 %4, %5\n\ts_addc_u32 %0, %2, %3\n\ts_addc_u32 %1, %6, 0"
+        : "=&s"(n0), "=s"(n1) : "s"(m1), "s"(c1), "s"(t), "s"(c0), "s"(m2) : "scc");
+}
+/* the wave-uniform value s into lane `l` of v (v_writelane_b32) */
+extern "C" __device__ int slip_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");     /* (clang has no builtin for it) */
+SLIP_DEV uint32_t slip_writelane(uint32_t v, uint32_t s, int l) { return (uint32_t) slip_llvm_writelane((int) s, l, (int) v); }
 /* wave shift by one lane with a wave-uniform value entering lane 0: zero-filling DPP move (no `old` operand to
  * set up) + v_writelane */
 SLIP_DEV uint32_t slip_dpp_shr1_in(uint32_t v, uint32_t in)

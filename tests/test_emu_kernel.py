@@ -193,3 +193,11 @@ def test_emulated_engine_off_and_candidates_only(emu_lib):
                            kmax=entry["kmax"], limb_cap=entry["cap"], waves=2, workers=5, lib_path=emu_lib, debug_flags=flags)
         check_against_golden(entry, fix, res)
         assert res["info"]["engine_commits"] == 0
+
+
+def test_emulated_hensel_division(emu_lib):
+    """wr_div_hensel (the exact division that needs no 2-adic inverse; wave_bigint_reg.h) on the CPU emulation of the wave
+    primitives, against Python integers: the same cases the device test runs (tests/test_gpu_parity.py)"""
+    import ctypes as C
+    import test_gpu_parity
+    test_gpu_parity._hensel_cases(C.CDLL(emu_lib))
