@@ -149,6 +149,19 @@ double slip_hip_factor_solve_ms(const slip_hip_factor *f);
  * the handle's own factors are untouched, so run / solve keep working on the local values. */
 int slip_hip_factor_rescale(slip_hip_factor *f, int32_t nscales, const int32_t *slen, const uint64_t *slimbs, void *stream);
 
+/* Subtree farm, last step ("completed L columns gathered", then the separator columns): the first K columns
+ * of THIS matrix's factorisation are given -- the blocks' columns, factorised on other handles / ranks and rescaled -- and
+ * slip_hip_factor_run continues with column K exactly as SLIP_LU_factorize.c:190-264 does from k = K.  L, U: the K columns in
+ * the form slip_hip_factor_download produces (column pointers Lp[K+1] / Up[K+1], ORIGINAL row ids in the reference's entry
+ * order, the pivot LAST in every U column, signed limb counts, limbs back to back); piv_row[K]: the pivot row of every
+ * column, from which the row permutation is replayed (slip_get_pivot.c:164-176).  The handle is reset first; K = 0 is a
+ * reset.  Host pointers, copied.  Inconsistent input (a pivot row that is already pivotal or missing from its column, an
+ * empty U column) is SLIP_HIP_INCORRECT_INPUT. */
+int slip_hip_factor_set_prefix(slip_hip_factor *f, int32_t K,
+                               const int64_t *Lp, const int32_t *Li, const int32_t *Llen, const uint64_t *Llimbs,
+                               const int64_t *Up, const int32_t *Ui, const int32_t *Ulen, const uint64_t *Ulimbs,
+                               const int32_t *piv_row);
+
 void slip_hip_factor_destroy(slip_hip_factor *f);
 
 /* Triplet files <-> limb slabs, host only.  read: what SLIP_tripread + SLIP_build_sparse_trip_mpz

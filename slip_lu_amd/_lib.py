@@ -34,7 +34,7 @@ EXPORTS = ("slip_hip_default_options", "slip_hip_device_count", "slip_hip_factor
            "slip_hip_factor_download", "slip_hip_factor_destroy", "slip_hip_matgen",
            "slip_hip_free", "slip_hip_wave_op_test", "slip_hip_version",
            "slip_hip_factor_phase_cycles", "slip_hip_factor_solve", "slip_hip_factor_solve_ms",
-           "slip_hip_factor_from_factors", "slip_hip_factor_rescale", "slip_hip_read_triplet", "slip_hip_write_triplet")
+           "slip_hip_factor_from_factors", "slip_hip_factor_rescale", "slip_hip_factor_set_prefix", "slip_hip_read_triplet", "slip_hip_write_triplet")
 
 _libs = {}
 
@@ -79,6 +79,8 @@ def load(path=None):
     lib.slip_hip_factor_from_factors.restype = C.c_int
     lib.slip_hip_factor_rescale.argtypes = [vp, C.c_int32, vp, vp, vp]
     lib.slip_hip_factor_rescale.restype = C.c_int
+    lib.slip_hip_factor_set_prefix.argtypes = [vp, C.c_int32] + [vp] * 9
+    lib.slip_hip_factor_set_prefix.restype = C.c_int
     lib.slip_hip_factor_solve_ms.argtypes = [vp]
     lib.slip_hip_factor_solve_ms.restype = C.c_double
     _libs[path] = lib

@@ -119,6 +119,21 @@ class Factorization:
             raise SlipError(rc, "slip_hip_factor_from_factors")
         return self
 
+    def set_prefix(self, K, fac, piv_row):
+        """The first K columns are given (slip_hip_factor_set_prefix): `fac` holds Lp/Li/Llen/Llimbs/Up/Ui/Ulen/Ulimbs of
+        those columns in the form `download()` returns, piv_row[k] the pivot row of column k; run() continues at column K."""
+        K = int(K)
+        arrs = [np.ascontiguousarray(fac[k], dtype=t) for k, t in (
+            ("Lp", np.int64), ("Li", np.int32), ("Llen", np.int32), ("Llimbs", np.uint64),
+            ("Up", np.int64), ("Ui", np.int32), ("Ulen", np.int32), ("Ulimbs", np.uint64))]
+        arrs.append(np.ascontiguousarray(piv_row, dtype=np.int32))
+        if K > 0 and (arrs[0].size < K + 1 or arrs[4].size < K + 1 or arrs[8].size < K):
+            raise SlipError(-3, "set_prefix: arrays shorter than K columns")
+        arrs = [a if a.size else np.zeros(1, a.dtype) for a in arrs]
+        rc = self.lib.slip_hip_factor_set_prefix(self.h, K, *[a.ctypes.data for a in arrs])
+        if rc:
+            raise SlipError(rc, "slip_hip_factor_set_prefix")
+
     def reset(self):
         rc = self.lib.slip_hip_factor_reset(self.h)
         if rc:

@@ -432,7 +432,43 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     const uint64_t dm = slip_ballot(lane < ncand && (int) cb[32 + 6 * lane] == diag_t);
                     slip_wave_sync_lds();
                     if (lane < ncand) { cb[32 + 6 * lane] = myrow; cb[32 + 6 * lane + 4] = mypos; }
-                    if (lane == 0) cb[23] = (uint32_t)(diag_t < 0 ? 0xFFu : (dm ? (uint32_t) slip_ctz64(dm) : 0xFEu));      /* 0xFF: no diagonal row; 0xFE: it is not among the candidates */
+                    const int dc = diag_t < 0 ? 0xFF : (dm ? slip_ctz64(dm) : 0xFE);      /* 0xFF: no diagonal row; 0xFE: it is not among the candidates */
+                    if (lane == 0) cb[23] = (uint32_t) dc;
+                    /* the choice itself, HERE, side by side for the columns of the batch: every comparison slip_get_pivot makes
+                     * is among this column's own candidates (class S: a * rho[j-1] with one rho for all, so |a| decides,
+                     * slip_get_smallest_pivot.c:58-101 / slip_get_largest_pivot.c; the diagonal rule, slip_get_pivot.c:68-146, is a
+                     * ratio of two of them).  Only a tie is broken by positions, which a swap earlier in this batch may still
+                     * change: such a column is chosen again in the serial step (word 24, bit 8). */
+                    {
+                        const bool isc = lane < ncand;
+                        const uint32_t c_a0 = isc ? cb[32 + 6 * lane + 1] : 0u, c_a1 = isc ? cb[32 + 6 * lane + 2] : 0u, c_ax = isc ? cb[32 + 6 * lane + 3] : 0u;
+                        const uint64_t av = (uint64_t) c_a0 | ((uint64_t) c_a1 << 32);
+                        const uint64_t mykey = isc ? (kind == 0 ? av : ~av) : ~0ull;
+                        const uint32_t mh = slip_wave_min_u32((uint32_t)(mykey >> 32));
+                        const uint32_t ml = slip_wave_min_u32((uint32_t)(mykey >> 32) == mh ? (uint32_t) mykey : 0xFFFFFFFFu);
+                        const uint64_t mk = ((uint64_t) mh << 32) | ml;
+                        const uint64_t tie = slip_ballot(isc && mykey == mk);
+                        uint32_t spec = 0;
+                        int bc = 0;
+                        if (slip_popc64(tie) > 1) spec = 0x100u;
+                        else if (!tie) spec = 0x400u;
+                        else {
+                            bc = slip_ctz64(tie);
+                            if (diagpref && dc != 0xFF && dc != bc) {
+                                if (dc == 0xFE) spec = 0x200u;               /* the diagonal row is not among the candidates sent: the worker decides */
+                                else if (scheme == 1 || P.tol_mode == 0) bc = dc;
+                                else {
+                                    const uint64_t ab = (uint64_t) slip_readlane(c_a0, bc) | ((uint64_t) slip_readlane(c_a1, bc) << 32);
+                                    const uint64_t ad = (uint64_t) slip_readlane(c_a0, dc) | ((uint64_t) slip_readlane(c_a1, dc) << 32);
+                                    const int tk = slip_tol_small(P.tol_m, P.tol_e, scheme == 3 ? ab : ad, scheme == 3 ? ad : ab);
+                                    if (tk < 0) spec = 0x200u; else if (tk) bc = dc;
+                                }
+                            }
+                        }
+                        const uint32_t s_row = slip_readlane(myrow, bc), s_a0 = slip_readlane(c_a0, bc), s_a1 = slip_readlane(c_a1, bc);
+                        const uint32_t s_ax = slip_readlane(c_ax, bc), s_pos = slip_readlane(mypos, bc);
+                        if (lane == 0) { cb[24] = spec | (uint32_t) bc; cb[25] = s_row; cb[26] = s_a0; cb[27] = s_a1; cb[28] = s_ax; cb[29] = s_pos; }
+                    }
                 }
             } else if (kindp == 1) {
                 if (!mirror || (int) cb[22] < 1 || (int) cb[22] > SLIP_PKG_FULLMAX || stamp0 < 1 || stamp0 - 1 < sv[C_PR0] || (hver[SLIP_CB + i] >> 8) != (uint32_t)(4 * (int) cb[22]) + (1u << 15)) hit = 1;
@@ -445,6 +481,39 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             if (tid == T - 3) sv64[SV_UNZ / 2] = slip_ld_i64(&P.Up[kc]);
             if (tid == T - 4) sv64[SV_UNL / 2] = slip_ld_i64(&P.Uo[kc]);
             if (tid == T - 5) *Mrec = slip_ld_piv(&P.piv[kc - 1]);       /* kc >= 1: column 0 is never packaged */
+        }
+        slip_block_sync();
+        /* (b2) a row of the pattern that becomes pivotal earlier in this batch sends the package back (the pivots before the batch
+         * were checked above).  The pivots chosen above are the ones the serial step commits -- or the batch ends before this column
+         * -- so each wave checks its column against them; columns whose pivot is not known yet (a tie, a full package) are left to
+         * the serial step (word 30: their mask) */
+        for (int i = wave; i < nb; i += nw) {
+            uint32_t *cb = cbuf + i * SLIP_CBW;
+            uint32_t unk = 0;
+            if (!cb[18] && cb[21] == 0u) {
+                const int nrows = (int) cb[16];
+                const uint32_t *rows = cb + 128;
+                uint32_t rr[SLIP_PKG_NROWMAX / SLIP_WAVE];
+#pragma unroll
+                for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) rr[q] = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
+                /* lane e: column kc + e's state */
+                const uint32_t *ce = cbuf + (lane < nb ? lane : 0) * SLIP_CBW;
+                const uint32_t e_pre = ce[18], e_kind = ce[21], e_spec = ce[24], e_row = ce[25];
+                const uint64_t known = slip_ballot(lane < i && !e_pre && e_kind == 0u && !(e_spec & 0x700u));
+                unk = (uint32_t)(slip_ballot(lane < i && !e_pre) & ~known);
+                int hit = 0;
+                for (int e = 0; e < i; e++) {
+                    const uint32_t r = slip_readlane(e_row, e);
+                    if ((known >> e) & 1ull) {
+#pragma unroll
+                        for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) if (rr[q] == r) hit = 1;
+                    }
+                }
+                const uint64_t anyhit = slip_ballot(hit);
+                slip_wave_sync_lds();
+                if (anyhit && lane == 0) cb[18] = 1u;
+            }
+            if (lane == 0) cb[30] = unk;
         }
         slip_block_sync();
         SLIP_CT(1);                                  /* 1: the packages into LDS */
@@ -488,7 +557,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 /* the row at position j (the one the pivot changes places with): as loaded at the start of the batch, or the row a
                  * swap of this batch displaced to j */
                 int intermed2 = HF(17);
-                for (int e = 0; e < i; e++) if ((int) slip_readlane(bs_opos, e) == j) intermed2 = (int) slip_readlane(bs_disp, e);
+                { const uint64_t pm_ = slip_ballot(lane < i && bs_opos == (uint32_t) j); if (pm_) intermed2 = (int) slip_readlane(bs_disp, 63 - slip_clz64(pm_)); }      /* (the last such swap counts) */
                 SLIP_CT(10);
                 if (!reject && kindp == 0) {
                     /* ---- kind 0: candidates only ---- */
@@ -502,23 +571,21 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     Lb_total = (uint64_t) nA * (uint64_t) slot + preserve + L_b;
                     const uint64_t Ub_total = U_l + preserve;
                     nLc = nrows - nUc_all;
-                    /* this lane's rows and its candidate: one round of reads */
-                    uint32_t rr[SLIP_PKG_NROWMAX / SLIP_WAVE];
+                    /* the choice was made when the package was loaded (word 24; bit 8: a tie, decided below by positions as they
+                     * are NOW), and the pattern was checked against the pivots of this batch that were known then; the others
+                     * (word 30: ties, full packages) are checked here */
+                    const uint32_t spec = (uint32_t) HF(24), unk = (uint32_t) HF(30);
+                    if (unk) {
+                        uint32_t rr[SLIP_PKG_NROWMAX / SLIP_WAVE];
 #pragma unroll
-                    for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) rr[q] = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
-                    const bool isc = lane < ncand;
-                    const uint32_t c_row = isc ? cands[6 * lane] : 0xFFFFFFFFu, c_a0 = isc ? cands[6 * lane + 1] : 0u, c_a1 = isc ? cands[6 * lane + 2] : 0u;
-                    const uint32_t c_ax = isc ? cands[6 * lane + 3] : 0u;
-                    uint32_t mypos = isc ? cands[6 * lane + 4] : BIG;
-                    /* a row of the pattern that has become pivotal in this batch: the package goes back (the pivots before the
-                     * batch were checked when it was loaded) */
-                    {
+                        for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) rr[q] = lane + 64 * q < nrows ? rows[lane + 64 * q] : 0xFFFFFFFFu;
                         int hit = 0;
                         for (int e = 0; e < i; e++) {
-                            const uint32_t r = slip_readlane(bs_row, e), d = slip_readlane(bs_disp, e), o = slip_readlane(bs_opos, e);
+                            const uint32_t r = slip_readlane(bs_row, e);
+                            if ((unk >> e) & 1u) {
 #pragma unroll
-                            for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) if (rr[q] == r) hit = 1;
-                            if (c_row == d) mypos = o;          /* ... and a candidate a swap of this batch displaced */
+                                for (int q = 0; q < SLIP_PKG_NROWMAX / SLIP_WAVE; q++) if (rr[q] == r) hit = 1;
+                            }
                         }
                         if (slip_ballot(hit)) reject = 1;
                     }
@@ -535,26 +602,30 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                         if (limb_cap_ > 0 && (int)((maxub_all + 63) >> 6) > limb_cap_) reject = 2;
                     }
                     SLIP_CT(12);
-                    int bc = 0;
-                    if (!reject) {
-                        /* the candidates are class-S values: a * rho[j-1] with the same rho for all, so |a| decides
-                         * (slip_get_smallest_pivot.c:58-101 / slip_get_largest_pivot.c); equal values by pattern position */
+                    uint32_t a0 = (uint32_t) HF(26), a1 = (uint32_t) HF(27), ax = (uint32_t) HF(28);
+                    e_pivrow = HF(25); e_pivpos = HF(29);
+                    if (!reject && (spec & 0x100u)) {
+                        /* a tie: equal values by pattern position (slip_get_smallest_pivot.c:58-101), the positions as the swaps of
+                         * this batch have left them; then the diagonal preference as above */
+                        const bool isc = lane < ncand;
+                        const uint32_t c_row = isc ? cands[6 * lane] : 0xFFFFFFFFu, c_a0 = isc ? cands[6 * lane + 1] : 0u, c_a1 = isc ? cands[6 * lane + 2] : 0u;
+                        const uint32_t c_ax = isc ? cands[6 * lane + 3] : 0u;
+                        uint32_t mypos = isc ? cands[6 * lane + 4] : BIG;
+                        for (int e = 0; e < i; e++) {
+                            const uint32_t d = slip_readlane(bs_disp, e), o = slip_readlane(bs_opos, e);
+                            if (c_row == d) mypos = o;
+                        }
                         const uint64_t av = (uint64_t) c_a0 | ((uint64_t) c_a1 << 32);
                         const uint64_t mykey = isc ? (kind == 0 ? av : ~av) : ~0ull;
                         const uint32_t mh = slip_wave_min_u32((uint32_t)(mykey >> 32));
                         const uint32_t ml = slip_wave_min_u32((uint32_t)(mykey >> 32) == mh ? (uint32_t) mykey : 0xFFFFFFFFu);
                         const uint64_t mk = ((uint64_t) mh << 32) | ml;
                         const uint64_t tie = slip_ballot(isc && mykey == mk);
-                        int est = 0;
-                        if (slip_popc64(tie) > 1) {
-                            const uint32_t bp = slip_wave_min_u32(((tie >> lane) & 1ull) ? mypos : BIG);
-                            const uint64_t bm_ = slip_ballot(((tie >> lane) & 1ull) && mypos == bp);
-                            est = bm_ ? 0 : SLIPDEV_INTERNAL;
-                            bc = bm_ ? slip_ctz64(bm_) : 0;
-                        } else if (tie) bc = slip_ctz64(tie);
-                        else est = SLIPDEV_INTERNAL;
-                        /* the diagonal preference (slip_get_pivot.c:68-76, 89-118, 126-146); the worker listed the diagonal row when it is
-                         * a nonzero non-pivotal row of the pattern; the common factor rho[j-1] cancels in the ratio */
+                        int est = 0, bc = 0;
+                        const uint32_t bp = slip_wave_min_u32(((tie >> lane) & 1ull) ? mypos : BIG);
+                        const uint64_t bm_ = slip_ballot(((tie >> lane) & 1ull) && mypos == bp);
+                        est = bm_ ? 0 : SLIPDEV_INTERNAL;
+                        bc = bm_ ? slip_ctz64(bm_) : 0;
                         const int dc = HF(23);
                         if (!est && diagpref && dc != 0xFF && dc != bc) {
                             if (dc == 0xFE) est = -1;                   /* not among the candidates it sent: the worker decides */
@@ -568,11 +639,20 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                         }
                         if (est > 0) { if (lane == 0) { if (!st->dbg_who) { st->dbg_who = 120; st->dbg_k = j; st->dbg_a = ncand; st->dbg_b = (int32_t) tie; } slip_raise_stop(st, 0, SLIPDEV_INTERNAL); } reject = 2; }
                         else if (est < 0) reject = 2;
+                        a0 = slip_readlane(c_a0, bc); a1 = slip_readlane(c_a1, bc); ax = slip_readlane(c_ax, bc);
+                        e_pivrow = (int) slip_readlane(c_row, bc); e_pivpos = (int) slip_readlane(mypos, bc);
+                    } else if (!reject) {
+                        if (spec & 0x400u) { if (lane == 0) { if (!st->dbg_who) { st->dbg_who = 120; st->dbg_k = j; st->dbg_a = ncand; st->dbg_b = (int32_t) spec; } slip_raise_stop(st, 0, SLIPDEV_INTERNAL); } reject = 2; }
+                        else if (spec & 0x200u) reject = 2;
+                        else {
+                            /* the pivot row may have been displaced by a swap of this batch: the last one counts */
+                            const uint64_t dm_ = slip_ballot(lane < i && bs_disp == (uint32_t) e_pivrow);
+                            if (dm_) e_pivpos = (int) slip_readlane(bs_opos, 63 - slip_clz64(dm_));
+                        }
                     }
                     SLIP_CT(13);
                     if (!reject) {
                         /* rho[j] = the pivot's one-limb value times rho[j-1]: into the stage slot (for the publish step) and into Ms */
-                        const uint32_t a0 = slip_readlane(c_a0, bc), a1 = slip_readlane(c_a1, bc), ax = slip_readlane(c_ax, bc);
                         const int nd = (int)((ax >> 12) & 3u);
                         if (lm <= 2) {
                             const slip_u128 y = (slip_u128)((uint64_t) a0 | ((uint64_t) a1 << 32)) * M.lo;
@@ -588,7 +668,6 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                             if (kind == 1) key = ~key;
                             pbits = (int)(key >> 40); lp_ = len;
                         }
-                        e_pivrow = (int) slip_readlane(c_row, bc); e_pivpos = (int) slip_readlane(mypos, bc);
                         pneg = (int)((ax >> 14) & 1u) ^ (M.len < 0);
                         plimbs = (uint64_t)((lp_ + 1) >> 1);
                         poff = lm > 2 ? Lnl_ + (int64_t)(ax & 0x3FFu) * slot : Lnl_ + (int64_t) nA * slot;

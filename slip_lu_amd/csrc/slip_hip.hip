@@ -1045,6 +1045,94 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     return SLIP_HIP_OK;
 }
 
+/* ---- continue from a prefix (the subtree farm's last step) ----
+ * The first K columns of the factorisation are GIVEN (the blocks' columns, factorised elsewhere and rescaled to the global
+ * pivot chain: slip_lu_amd/parallel.py): L(:,k), U(:,k) in the reference's CSC with ORIGINAL row ids and the pivot row of
+ * every column.  The handle is put into the state a launch that stopped at column K leaves -- the permutation replayed from
+ * the pivot rows (slip_get_pivot.c:164-176), the pivots' records, the column pointers, every given column ready -- and
+ * slip_hip_factor_run goes on with column K (the separator columns of the farm), SLIP_LU_factorize.c:190-264 from k = K. */
+extern "C" int slip_hip_factor_set_prefix(slip_hip_factor *f, int32_t K,
+                                          const int64_t *Lp, const int32_t *Li, const int32_t *Llen, const uint64_t *Llimbs,
+                                          const int64_t *Up, const int32_t *Ui, const int32_t *Ulen, const uint64_t *Ulimbs,
+                                          const int32_t *piv_row)
+{
+    if (!f || f->factors_only || K < 0 || K > f->n) return SLIP_HIP_INCORRECT_INPUT;
+    if (K > 0 && (!Lp || !Li || !Llen || !Llimbs || !Up || !Ui || !Ulen || !Ulimbs || !piv_row)) return SLIP_HIP_INCORRECT_INPUT;
+    { const int e = slip_hip_factor_reset(f); if (e) return e; }
+    if (K == 0) return SLIP_HIP_OK;
+    SlipParams *P = &f->P;
+    const int32_t n = f->n;
+    const int64_t lnz = Lp[K], unz = Up[K];
+    if (Lp[0] != 0 || Up[0] != 0 || lnz < K || unz < K) return SLIP_HIP_INCORRECT_INPUT;
+    int32_t *pinv = (int32_t *) malloc((size_t) n * 4), *rowperm = (int32_t *) malloc((size_t) n * 4);
+    int32_t *swr = (int32_t *) malloc((size_t) K * 4), *swp = (int32_t *) malloc((size_t) K * 4), *ready = (int32_t *) malloc((size_t) K * 4);
+    SlipEnt *Le = (SlipEnt *) malloc((size_t) lnz * sizeof(SlipEnt)), *Ue = (SlipEnt *) malloc((size_t) unz * sizeof(SlipEnt));
+    SlipPiv *piv = (SlipPiv *) calloc((size_t) K, sizeof(SlipPiv));
+    int64_t *Lo = (int64_t *) malloc(((size_t) K + 1) * 8), *Uo = (int64_t *) malloc(((size_t) K + 1) * 8);
+    int rc = SLIP_HIP_OK;
+#define FREE_ALL_() do { free(pinv); free(rowperm); free(swr); free(swp); free(ready); free(Le); free(Ue); free(piv); free(Lo); free(Uo); } while (0)
+    if (!pinv || !rowperm || !swr || !swp || !ready || !Le || !Ue || !piv || !Lo || !Uo) { FREE_ALL_(); return SLIP_HIP_OUT_OF_MEMORY; }
+    int bad = 0;
+    for (int64_t t = 0; t < lnz && !bad; t++) if (Li[t] < 0 || Li[t] >= n) bad = 1;
+    for (int64_t t = 0; t < unz && !bad; t++) if (Ui[t] < 0 || Ui[t] >= n) bad = 1;
+    int32_t maxdig = 1; int64_t lnl = 0, unl = 0;
+    if (!bad) { slab_to_entries(lnz, Llen, Llimbs, Le, &maxdig, &lnl); slab_to_entries(unz, Ulen, Ulimbs, Ue, &maxdig, &unl); }
+    /* the permutation: column k's pivot row changes places with the row at position k (slip_get_pivot.c:164-176) */
+    for (int32_t i = 0; i < n; i++) { pinv[i] = i; rowperm[i] = i; }
+    for (int32_t k = 0; k < K && !bad; k++) {
+        const int32_t r = piv_row[k];
+        if (r < 0 || r >= n || pinv[r] < k || Lp[k + 1] < Lp[k] || Up[k + 1] <= Up[k]) { bad = 1; break; }
+        const int32_t p = pinv[r], d = rowperm[k];
+        swr[k] = d; swp[k] = p; ready[k] = 1;
+        rowperm[k] = r; rowperm[p] = d; pinv[r] = k; pinv[d] = p;
+        if (p == k) { pinv[r] = k; rowperm[k] = r; }
+        /* rho_k is the entry of L(:,k) in the pivot row (slip_get_pivot.c:178-182), and the last entry of U(:,k) */
+        int64_t at = -1;
+        for (int64_t t = Lp[k]; t < Lp[k + 1]; t++) if (Li[t] == r) at = t;
+        if (at < 0 || Le[at].len == 0 || Ui[Up[k + 1] - 1] != r) { bad = 1; break; }
+        const uint64_t *pv = Llimbs + Le[at].off;
+        const int32_t dig = Le[at].len < 0 ? -Le[at].len : Le[at].len;
+        int z = 0; { int64_t w = 0; while (pv[w] == 0) { w++; z += 64; } z += __builtin_ctzll(pv[w]); }
+        SlipPiv pr; memset(&pr, 0, sizeof pr);
+        pr.off = Le[at].off; pr.len = Le[at].len; pr.bits = Le[at].bits; pr.ctz = z; pr.invlen = 0; pr.lo = pv[0];
+        if (dig <= 2) { uint64_t dd = pr.lo >> z, x = dd; for (int q = 0; q < 5; q++) x *= 2 - dd * x; pr.inv64 = x; }
+        piv[k] = pr;
+    }
+    if (!bad) for (int32_t k = 0; k <= K; k++) { Lo[k] = k < K ? Le[Lp[k]].off : lnl; Uo[k] = k < K ? Ue[Up[k]].off : unl; }
+    if (bad) { FREE_ALL_(); return SLIP_HIP_INCORRECT_INPUT; }
+    /* room for the prefix and as much again (the run doubles a slab that fills up) */
+    if (lnz + n > P->Lcap_nz || lnl + n > P->Lcap_nl) {
+        const int64_t nz = 2 * (lnz + n), nl = 2 * (lnl + n);
+        if ((rc = dev_grow(&P->Li, 0, nz)) || (rc = dev_grow(&P->Le, 0, nz)) || (rc = dev_grow(&P->Llimbs, 0, nl))) { FREE_ALL_(); return rc; }
+        P->Lcap_nz = nz; P->Lcap_nl = nl;
+    }
+    if (unz + n > P->Ucap_nz || unl + n > P->Ucap_nl) {
+        const int64_t nz = 2 * (unz + n), nl = 2 * (unl + n);
+        if ((rc = dev_grow(&P->Ui, 0, nz)) || (rc = dev_grow(&P->Ue, 0, nz)) || (rc = dev_grow(&P->Ulimbs, 0, nl))) { FREE_ALL_(); return rc; }
+        P->Ucap_nz = nz; P->Ucap_nl = nl;
+    }
+#define UP_(dst, src, bytes) do { if (!rc && (bytes) > 0 && hipMemcpy((void *)(dst), (src), (size_t)(bytes), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR; } while (0)
+    UP_(P->pinv, pinv, (size_t) n * 4); UP_(P->row_perm, rowperm, (size_t) n * 4); UP_(P->piv, piv, (size_t) K * sizeof(SlipPiv));
+    UP_(P->sw_row, swr, (size_t) K * 4); UP_(P->sw_pos, swp, (size_t) K * 4); UP_(P->Lready, ready, (size_t) K * 4);
+    UP_(P->Lp, Lp, ((size_t) K + 1) * 8); UP_(P->Lo, Lo, ((size_t) K + 1) * 8); UP_(P->Li, Li, (size_t) lnz * 4); UP_(P->Le, Le, (size_t) lnz * sizeof(SlipEnt)); UP_(P->Llimbs, Llimbs, (size_t) lnl * 8);
+    UP_(P->Up, Up, ((size_t) K + 1) * 8); UP_(P->Uo, Uo, ((size_t) K + 1) * 8); UP_(P->Ui, Ui, (size_t) unz * 4); UP_(P->Ue, Ue, (size_t) unz * sizeof(SlipEnt)); UP_(P->Ulimbs, Ulimbs, (size_t) unl * 8);
+    if (!rc) {
+        SlipState *h = &f->hs;
+        h->F = K; h->Fpiv = piv_row[K - 1]; h->F2 = K; h->k_next = K; h->status_k = K;
+        h->Lnz = lnz; h->Unz = unz; h->Lnl = lnl; h->Unl = unl; h->Lnl_exact = lnl; h->Unl_exact = unl;
+        h->c_maxdig = (unsigned long long) maxdig;
+        rc = upload_state(f, 0);
+        if (!rc && hipStreamSynchronize(0) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    }
+#undef UP_
+    FREE_ALL_();
+#undef FREE_ALL_
+    /* values wider than the private x rows were sized for: the stride grows now rather than in the first launch */
+    if (!rc && 2 * (int64_t) maxdig + 8 > P->xcap) rc = grow_x_keep(f, 2 * (int64_t) maxdig + 8, K);
+    f->last_status = rc;
+    return rc;
+}
+
 /* ---- REF triangular solves on the resident factors (SLIP_LU_solve.c:41-86) ---- */
 static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, int32_t *rhs_done, hipStream_t stream)
 {

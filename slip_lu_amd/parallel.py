@@ -281,6 +281,155 @@ def farm_factorize(dist, n, Ap, Ai, Ax, q, blocks, kcols=0, device="cpu", make=N
     return mine, owner, sigma
 
 
+# ---------------------------------------------------------------------------------------------
+# Farm completion ("completed L columns gathered", then the separator columns)
+# ---------------------------------------------------------------------------------------------
+_FKEYS = (("Lp", np.int64), ("Li", np.int32), ("Llen", np.int32), ("Up", np.int64), ("Ui", np.int32), ("Ulen", np.int32), ("pinv", np.int32))
+
+
+def allgather_i64(dist, arr, device="cpu"):
+    """All-gather one variable-length int64 array per rank (sizes first, then the padded payload): [array] by rank."""
+    mine = np.ascontiguousarray(arr, dtype=np.int64)
+    if dist is None:
+        return [mine]
+    import torch
+    world = dist.get_world_size()
+    size = torch.tensor([mine.size], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    cap = max(1, int(max(int(s.item()) for s in sizes)))
+    pad = torch.zeros(cap, dtype=torch.int64, device=device)
+    if mine.size:
+        pad[:mine.size] = torch.from_numpy(mine).to(device)
+    outs = [torch.zeros(cap, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return [o.cpu().numpy()[:int(s.item())].copy() for o, s in zip(outs, sizes)]
+
+
+def pack_factors(mine):
+    """{block: canonical factor dict} -> one int64 buffer: per block [t, n_local, K, lnz, unz, lnl, unl], the index arrays,
+    the two limb slabs (uint64 viewed as int64) -- the wire format of the gathered columns"""
+    parts = [np.array([len(mine)], dtype=np.int64)]
+    for t in sorted(mine):
+        d = mine[t]
+        K = int(d["K"])
+        lnz, unz = int(d["Lp"][K]), int(d["Up"][K])
+        lnl, unl = int(np.abs(np.asarray(d["Llen"][:lnz], dtype=np.int64)).sum()), int(np.abs(np.asarray(d["Ulen"][:unz], dtype=np.int64)).sum())
+        parts.append(np.array([t, int(d["n"]), K, lnz, unz, lnl, unl], dtype=np.int64))
+        for key, size in (("Lp", K + 1), ("Li", lnz), ("Llen", lnz), ("Up", K + 1), ("Ui", unz), ("Ulen", unz), ("pinv", int(d["n"]))):
+            parts.append(np.asarray(d[key][:size], dtype=np.int64))
+        parts.append(np.asarray(d["Llimbs"][:lnl], dtype=np.uint64).view(np.int64))
+        parts.append(np.asarray(d["Ulimbs"][:unl], dtype=np.uint64).view(np.int64))
+    return np.concatenate(parts)
+
+
+def unpack_factors(buf):
+    buf = np.asarray(buf, dtype=np.int64)
+    out, o = {}, 1
+    for _ in range(int(buf[0])):
+        t, nl_, K, lnz, unz, lnl, unl = (int(v) for v in buf[o:o + 7]); o += 7
+        d = dict(n=nl_, K=K)
+        for (key, dt), size in zip(_FKEYS, (K + 1, lnz, lnz, K + 1, unz, unz, nl_)):
+            d[key] = buf[o:o + size].astype(dt); o += size
+        d["Llimbs"] = buf[o:o + lnl].view(np.uint64).copy(); o += lnl
+        d["Ulimbs"] = buf[o:o + unl].view(np.uint64).copy(); o += unl
+        out[t] = d
+    return out
+
+
+def allgather_factors(dist, mine, device="cpu"):
+    """every rank's rescaled block columns on every rank: {block: canonical factor dict} (ONE all-gather of the packed
+    columns: RCCL on `device`="cuda" tensors under nccl, gloo on CPU tensors in the tests)"""
+    out = {}
+    for buf in allgather_i64(dist, pack_factors(mine), device=device):
+        out.update(unpack_factors(buf))
+    return out
+
+
+def assemble_prefix(n, blocks, q, facs, owner):
+    """The first K = len(owner) columns of the WHOLE matrix's factorisation from the blocks' rescaled columns, in the form
+    slip_hip_factor_set_prefix takes: global row ids and the reference's entry order, which is an order of GLOBAL positions
+    (slip_sort_xi sorts the pattern by pinv before the pivot search; the output loop of SLIP_LU_factorize.c:226-263 walks
+    it in that order after the swap): U(:,k) = the rows pivotal before k by position, then the pivot; L(:,k) = the other
+    rows by their position BEFORE column k's swap.  The positions come from replaying the swaps (slip_get_pivot.c:164-176).
+    Returns (factor dict with Lp/Li/Llen/Llimbs/Up/Ui/Ulen/Ulimbs, piv_row)."""
+    K = len(owner)
+    pinv = list(range(n)); row_at = list(range(n))
+    done = [0] * len(blocks)
+    off = {}
+    for t, d in facs.items():
+        lo = np.concatenate([[0], np.cumsum(np.abs(np.asarray(d["Llen"], dtype=np.int64)))])
+        uo = np.concatenate([[0], np.cumsum(np.abs(np.asarray(d["Ulen"], dtype=np.int64)))])
+        off[t] = (lo, uo)
+    out = {k: [] for k in ("Li", "Llen", "Llimbs", "Ui", "Ulen", "Ulimbs")}
+    Lp, Up, piv_row = [0], [0], []
+    for k in range(K):
+        t = owner[k]; kl = done[t]; done[t] += 1
+        d, ids = facs[t], blocks[t]
+        lo, uo = off[t]
+        inv_local = np.argsort(d["pinv"])                       # local position -> local row
+        prow = int(ids[int(inv_local[kl])])
+        ent_l = [(pinv[int(ids[int(d["Li"][p])])], int(ids[int(d["Li"][p])]), p) for p in range(int(d["Lp"][kl]), int(d["Lp"][kl + 1]))]
+        ent_u = [(pinv[int(ids[int(d["Ui"][p])])], int(ids[int(d["Ui"][p])]), p) for p in range(int(d["Up"][kl]), int(d["Up"][kl + 1]))]
+        ent_l.sort()
+        ent_u = sorted(e for e in ent_u if e[1] != prow) + [e for e in ent_u if e[1] == prow]
+        for _, r, p in ent_l:
+            out["Li"].append(r); out["Llen"].append(int(d["Llen"][p])); out["Llimbs"].append(d["Llimbs"][int(lo[p]):int(lo[p + 1])])
+        for _, r, p in ent_u:
+            out["Ui"].append(r); out["Ulen"].append(int(d["Ulen"][p])); out["Ulimbs"].append(d["Ulimbs"][int(uo[p]):int(uo[p + 1])])
+        Lp.append(len(out["Li"])); Up.append(len(out["Ui"]))
+        piv_row.append(prow)
+        p_, d_ = pinv[prow], row_at[k]
+        row_at[k], row_at[p_] = prow, d_
+        pinv[prow], pinv[d_] = k, p_
+        if p_ == k:
+            pinv[prow] = k; row_at[k] = prow
+    fac = dict(Lp=np.array(Lp, np.int64), Up=np.array(Up, np.int64),
+               Li=np.array(out["Li"], np.int32), Ui=np.array(out["Ui"], np.int32),
+               Llen=np.array(out["Llen"], np.int32), Ulen=np.array(out["Ulen"], np.int32),
+               Llimbs=np.concatenate(out["Llimbs"]).astype(np.uint64) if out["Llimbs"] else np.zeros(0, np.uint64),
+               Ulimbs=np.concatenate(out["Ulimbs"]).astype(np.uint64) if out["Ulimbs"] else np.zeros(0, np.uint64))
+    return fac, np.array(piv_row, np.int32)
+
+
+def farm_complete(dist, n, Ap, Ai, Ax, q, t, device="cpu", make=None, finish_on=0, **kw):
+    """The subtree farm end to end: the independent components of the leading t columns of q are factorised on
+    their ranks (farm_factorize), their rescaled columns are all-gathered, and rank `finish_on` (None: every rank) puts them
+    into a handle of the WHOLE matrix as its first K columns (slip_hip_factor_set_prefix) and factorises the remaining
+    columns -- the separator -- from there.  Returns the canonical factor dict of the whole matrix on the finishing rank(s),
+    None elsewhere; equal to factorising the whole matrix in one piece.  t is cut back to the leading columns that belong to
+    farmable components."""
+    import slip_lu_amd as sl
+    rank, world, _ = env_rank()
+    qi = [int(c) for c in q]
+    while t > 0:
+        blocks, rest = leading_blocks(n, Ap, Ai, qi, t)
+        rs = set(rest)
+        bad = [k for k in range(t) if qi[k] in rs]
+        if not bad:
+            break
+        t = bad[0]
+    if t <= 0:
+        blocks = []
+    facs, owner = {}, []
+    if blocks:
+        mine, owner, _ = farm_factorize(dist, n, Ap, Ai, Ax, q, blocks, device=device, make=make, **kw)
+        facs = allgather_factors(dist, mine, device=device)
+    if finish_on is not None and rank != finish_on:
+        return None
+    alen, alimbs = sl.ints_to_slab(np.asarray(Ax, dtype=np.int64))
+    f = (make or sl.Factorization)(n, Ap, Ai, alen, alimbs, np.asarray(q, dtype=np.int32), **kw)
+    if owner:
+        fac, piv_row = assemble_prefix(n, blocks, qi, facs, owner)
+        f.set_prefix(len(owner), fac, piv_row)
+    f.run()
+    res = f.download()
+    res.update(f.info())
+    res["farm_prefix"] = len(owner)
+    f.close()
+    return res
+
+
 def _to_ints(lens, limbs):
     out, o = [], 0
     for l in lens:

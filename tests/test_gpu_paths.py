@@ -123,3 +123,35 @@ def test_gpu_two_handles_run_concurrently():
     for h in streams:
         hip.hipStreamDestroy(h)
     assert not errs, errs
+
+
+@pytest.mark.parametrize("name,K", [("gen_n40", 15), ("10teams", 60), ("prob159", 400), ("NSR8K_w600", 300), ("gen_n2000_pm1", 1200)])
+def test_gpu_continue_from_a_given_prefix(name, K):
+    """slip_hip_factor_set_prefix on the device: K columns given, the rest factorised on top of them = the reference's factors"""
+    import slip_lu_amd as sl
+    entry, fix, a = _factor(name)
+    _, _, b = _factor(name)
+    try:
+        a.run(K)
+        d = a.download()
+        assert d["K"] == K
+        b.set_prefix(K, d, np.argsort(d["pinv"])[:K])
+        assert b.info()["K"] == K
+        rc = b.run(entry["kmax"], check=False)
+        res = b.download(); res.update(b.info()); res["status"] = rc
+        assert rc == entry["status"]
+        check_against_golden(entry, fix, res, counters=False)
+    finally:
+        a.close(); b.close()
+
+
+def test_gpu_farm_complete():
+    """SURVEY 8(e) end to end on the device: the blocks' columns (factorised, rescaled, gathered -- world 1 here) become the
+    prefix of the whole matrix's handle, which factorises the separator columns: equal to the whole-matrix oracle"""
+    import test_subtree_farm as T
+    from slip_lu_amd import parallel
+    n, Ap, Ai, Ax, q, n0 = T.make_bordered((9, 14, 11, 7, 12), 6, 5, bits=12)
+    whole = T.oracle_factor(n, Ap, Ai, Ax, q)
+    got = parallel.farm_complete(None, n, Ap, Ai, Ax, q, n0)
+    assert got["farm_prefix"] == n0 and got["K"] == n
+    T.same_factors(got, whole)

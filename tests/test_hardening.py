@@ -129,3 +129,43 @@ def test_create_rejects_dimensions_beyond_the_protocol_fields(emu_lib):
     one = np.zeros(2, np.int64)
     rc = lib.slip_hip_factor_create(C.byref(h), (1 << 24) - 1, one.ctypes.data, one.ctypes.data, one.ctypes.data, one.ctypes.data, one.ctypes.data, None)
     assert rc == -3 and not h.value
+
+
+@pytest.mark.parametrize("name,K", [("gen_n40", 15), ("gen_n40", 40), ("gen_n40", 0), ("test_mat_p4tol", 4), ("10teams", 60)])
+def test_continue_from_a_given_prefix(emu_lib, name, K):
+    """slip_hip_factor_set_prefix: the first K columns are given (here: taken from a run that stopped at K), the handle goes
+    on from column K and ends with the reference's factors -- SLIP_LU_factorize.c:190-264 entered at k = K"""
+    import slip_lu_amd as sl
+    entry, fix = load_case(name)
+    kw = dict(pivot=entry["pivot"], tol=entry["tol"], limb_cap=entry["cap"], waves=2, workers=4, lib_path=emu_lib)
+    a = sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], **kw)
+    b = sl.Factorization(entry["n"], fix["Ap"], fix["Ai"], fix["Alen"], fix["Alimbs"], fix["q"], **kw)
+    try:
+        if K:
+            a.run(K)
+            d = a.download()
+        else:
+            d = dict(Lp=[0], Li=[], Llen=[], Llimbs=[], Up=[0], Ui=[], Ulen=[], Ulimbs=[], pinv=np.arange(entry["n"]))
+        piv_row = np.argsort(d["pinv"])[:K]
+        b.run(3)                                   # whatever the handle held before is dropped
+        b.set_prefix(K, d, piv_row)
+        assert b.info()["K"] == K
+        b.run(entry["kmax"])
+        res = b.download(); res.update(b.info())
+        check_against_golden(entry, fix, res, counters=False)
+        if K >= 2:
+            # inconsistent input is refused: a pivot row named twice; a pivot row that is not in its column
+            bad = piv_row.copy(); bad[1] = bad[0]
+            with pytest.raises(sl.SlipError) as ei:
+                b.set_prefix(K, d, bad)
+            assert ei.value.code == -3
+            bad = piv_row.copy(); bad[0] = next(r for r in range(entry["n"]) if r not in set(int(v) for v in d["Li"][d["Lp"][0]:d["Lp"][1]]) | {int(piv_row[0])}) if d["Lp"][1] < entry["n"] else bad[0]
+            if bad[0] != piv_row[0]:
+                with pytest.raises(sl.SlipError):
+                    b.set_prefix(K, d, bad)
+            # and the handle still works afterwards
+            b.set_prefix(K, d, piv_row)
+            b.run(entry["kmax"])
+            check_against_golden(entry, fix, dict(b.download(), **b.info()), counters=False)
+    finally:
+        a.close(); b.close()

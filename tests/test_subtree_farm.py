@@ -277,3 +277,154 @@ def test_farm_factorize_two_ranks_gloo():
     import json
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["ok"] == 2 and res["world"] == 2 and res["cols"] == 25 and res["blocks"] == 5 and 0 < res["mine0"] < 5, res
+
+
+# ---------------------------------------------------------------------------------------------
+# Farm completion: blocks on their ranks, gathered, then the separator columns on top of them
+# ---------------------------------------------------------------------------------------------
+def make_bordered(sizes, border, seed, bits=8, density=0.6):
+    """bordered block-diagonal integer matrix: independent diagonal blocks (ids interleaved) plus `border` separator columns
+    with entries in every block's rows (and a dense border-by-border corner); q eliminates the blocks' columns first (in a
+    random interleaving), the border last"""
+    rng = np.random.default_rng(seed)
+    n0 = sum(sizes); n = n0 + border
+    ids = rng.permutation(n)
+    cols = [[] for _ in range(n)]
+    val = lambda: int(rng.integers(1, 2 ** bits)) * (1 if rng.random() < 0.5 else -1)
+    o = 0
+    for s in sizes:
+        blk = ids[o:o + s]; o += s
+        for a in range(s):
+            for b in range(s):
+                if a == b or rng.random() < density:
+                    cols[int(blk[b])].append((int(blk[a]), val()))
+    bord = [int(v) for v in ids[n0:]]
+    inner = [int(v) for v in ids[:n0]]
+    for b in bord:
+        for i in inner:
+            if rng.random() < 0.5:
+                cols[b].append((i, val()))          # border column, block row (a block column with a border row could take its
+                                                    # pivot there: such a component is not farmable, leading_blocks leaves it out)
+        for b2 in bord:
+            if b2 == b or rng.random() < 0.7:
+                cols[b].append((b2, val()))
+    Ap, Ai, Ax = [0], [], []
+    for j in range(n):
+        rng.shuffle(cols[j])
+        for i, v in cols[j]:
+            Ai.append(i); Ax.append(v)
+        Ap.append(len(Ai))
+    q = np.array([inner[t] for t in rng.permutation(n0)] + [bord[t] for t in rng.permutation(border)], np.int32)
+    return n, np.array(Ap, np.int64), np.array(Ai, np.int32), np.array(Ax, np.int64), q, n0
+
+
+def same_factors(a, b):
+    import slabfile
+    for k in slabfile.FACTOR_KEYS:
+        if k in a and k in b:
+            assert np.array_equal(np.asarray(a[k]).astype(np.int64), np.asarray(b[k]).astype(np.int64)), k
+    assert a["K"] == b["K"]
+
+
+def test_prefix_assembly_reproduces_the_reference_order():
+    """assemble_prefix's entry order (global positions replayed from the pivot rows) on a block-diagonal matrix: the assembled
+    columns are the whole-matrix oracle's arrays word for word -- the form slip_hip_factor_set_prefix takes"""
+    n, Ap, Ai, Ax = make_blocked((3, 5, 4, 6), 23)
+    q = np.random.default_rng(24).permutation(n).astype(np.int32)
+    whole = oracle_factor(n, Ap, Ai, Ax, q)
+    blocks, rest = parallel.leading_blocks(n, Ap, Ai, q, n)
+    assert rest == []
+
+    class OracleHandle:                 # the oracle behind the handle interface farm_factorize drives
+        def __init__(self, n_, Ap_, Ai_, Alen_, Alimbs_, q_, **kw):
+            self.args = (n_, Ap_, Ai_, Alen_, Alimbs_, q_)
+        def run(self, kmax=0):
+            self.r = oracle_lib.factorize(*self.args)
+        def download(self):
+            return self.r
+        def rescale(self, scales):
+            r = self.r
+            Lx = oracle_lib.bigints(r["Llen"], r["Llimbs"]); Ux = oracle_lib.bigints(r["Ulen"], r["Ulimbs"])
+            pinv = r["pinv"]
+            Lx = [v * scales[k] for k in range(r["K"]) for v in Lx[r["Lp"][k]:r["Lp"][k + 1]]]
+            Ux = [Ux[p] * scales[int(pinv[int(r["Ui"][p])])] for k in range(r["K"]) for p in range(r["Up"][k], r["Up"][k + 1])]
+            for key, vals in (("L", Lx), ("U", Ux)):
+                lens, limbs = [], []
+                for v in vals:
+                    a = abs(v); l = []
+                    while a:
+                        l.append(a & (2 ** 64 - 1)); a >>= 64
+                    lens.append(len(l) if v >= 0 else -len(l)); limbs += l
+                r[key + "len"] = np.array(lens, np.int32); r[key + "limbs"] = np.array(limbs, np.uint64)
+        def close(self):
+            pass
+    mine, owner, sigma = parallel.farm_factorize(None, n, Ap, Ai, Ax, q, blocks, make=OracleHandle)
+    facs = parallel.unpack_factors(parallel.pack_factors(mine))           # through the wire format
+    fac, piv_row = parallel.assemble_prefix(n, blocks, [int(c) for c in q], facs, owner)
+    assert [int(v) for v in piv_row] == [int(v) for v in np.argsort(whole["pinv"])]
+    for k in ("Lp", "Li", "Llen", "Llimbs", "Up", "Ui", "Ulen", "Ulimbs"):
+        assert np.array_equal(np.asarray(fac[k]).astype(np.int64), np.asarray(whole[k])[:len(fac[k])].astype(np.int64)), k
+
+
+def test_farm_complete_on_emulator():
+    """blocks -> rescale -> gather -> slip_hip_factor_set_prefix -> the separator columns, with the CPU emulation build of the
+    kernel source: equal to the oracle's factorisation of the whole bordered matrix"""
+    import slip_lu_amd as sl
+    emu = os.path.join(ROOT, "tests", "emu", "libslip_emu.so")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libslip_emu.so"])
+
+    def make(n, Ap, Ai, Alen, Alimbs, q, **kw):
+        return sl.Factorization(n, Ap, Ai, Alen, Alimbs, q, lib_path=emu, waves=2, workers=3, **kw)
+    n, Ap, Ai, Ax, q, n0 = make_bordered((4, 6, 5), 4, 77)
+    whole = oracle_factor(n, Ap, Ai, Ax, q)
+    got = parallel.farm_complete(None, n, Ap, Ai, Ax, q, n0, make=make)
+    assert got["farm_prefix"] == n0
+    same_factors(got, whole)
+    # a leading window that cuts a component: the farm takes what is farmable and the handle does the rest
+    got = parallel.farm_complete(None, n, Ap, Ai, Ax, q, n0 - 1, make=make)
+    assert 0 <= got["farm_prefix"] < n0
+    same_factors(got, whole)
+
+
+WORKER_COMPLETE = textwrap.dedent('''
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import slip_lu_amd as sl
+    from slip_lu_amd import parallel
+    import test_subtree_farm as T
+    dist = parallel.init("gloo")
+    rank, world, _ = parallel.env_rank()
+    emu = os.path.join({root!r}, "tests", "emu", "libslip_emu.so")
+    n, Ap, Ai, Ax, q, n0 = T.make_bordered((5, 3, 6, 4), 3, 91)
+
+    def make(n_, Ap_, Ai_, Alen_, Alimbs_, q_, **kw):
+        return sl.Factorization(n_, Ap_, Ai_, Alen_, Alimbs_, q_, lib_path=emu, waves=1, workers=2, **kw)
+    got = parallel.farm_complete(dist, n, Ap, Ai, Ax, q, n0, make=make, finish_on=0)
+    ok = 1
+    if rank == 0:
+        whole = T.oracle_factor(n, Ap, Ai, Ax, q)
+        T.same_factors(got, whole)
+        print(json.dumps(dict(ok=1, world=world, prefix=got["farm_prefix"], K=got["K"])))
+    else:
+        assert got is None
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+''')
+
+
+def test_farm_complete_two_ranks_gloo():
+    """the farm end to end with two ranks (gloo; the emulator build stands in for the GPU): each rank factorises its blocks,
+    the rescaled columns are all-gathered, rank 0 continues with the separator columns -- equal to the whole-matrix oracle"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libslip_emu.so"])
+    path = os.path.join("/tmp", f"slip_farm3_worker_{os.getpid()}.py")
+    open(path, "w").write(WORKER_COMPLETE.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29549", path],
+                         capture_output=True, text=True, env=env, timeout=900)
+    os.unlink(path)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] == 1 and res["world"] == 2 and res["prefix"] == 18 and res["K"] == 21, res
