@@ -1032,7 +1032,11 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                         }
                         /* (lanes of ONE store instruction to one address have no order: when the pivot already sits at position j,
                          * lanes 0/1 and 2/3 write identical values) */
+#ifndef SLIP_EMU_BUG_PERM
                         if (a4) slip_st_u32(a4, v4);
+#else
+                        (void) a4; (void) v4;      /* test build: the round-3 race put back (the swaps stored by the publishing waves below) */
+#endif
                     }
                     slip_wave_sync_lds();
                 }
@@ -1089,6 +1093,12 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 if (a8) slip_st_u64(a8, v8);
                 uint32_t *a4 = (uint32_t *) 0; uint32_t v4 = 0;
                 switch (lane) {
+#ifdef SLIP_EMU_BUG_PERM
+                    case 0: a4 = (uint32_t *) &P.row_perm[j]; v4 = (uint32_t) e_pivrow; break;
+                    case 1: a4 = (uint32_t *) &P.row_perm[e_pivpos]; v4 = (uint32_t) intermed2; break;
+                    case 2: a4 = (uint32_t *) &P.pinv[e_pivrow]; v4 = (uint32_t) j; break;
+                    case 3: a4 = (uint32_t *) &P.pinv[intermed2]; v4 = (uint32_t) e_pivpos; break;
+#endif
                     case 4: a4 = (uint32_t *) &P.sw_row[j]; v4 = (uint32_t) intermed2; break;
                     case 5: a4 = (uint32_t *) &P.sw_pos[j]; v4 = (uint32_t) e_pivpos; break;
                     case 6: a4 = mbx + SLIP_PKG_OUT + 1; v4 = (uint32_t) e_pivrow; break;

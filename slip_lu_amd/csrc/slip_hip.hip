@@ -826,6 +826,8 @@ static int grow_x_keep(slip_hip_factor *f, int64_t xcap, int32_t K)
 #ifdef SLIP_EMULATE
 static unsigned long long slip_emu_seed = 1;
 extern "C" void slip_emu_set_seed(unsigned long long s) { slip_emu_seed = s; }
+/* weak-store mode of the emulator (tests/emu/fiber_emu.h): sc1 stores land late and out of order */
+extern "C" void slip_emu_set_weak(int on) { emu::set_weak(on); }
 /* overwrite the length of entry t of L (isU 0) or U (isU 1): what a protocol error on the device would leave behind */
 extern "C" int slip_emu_corrupt_entry(slip_hip_factor *f, int isU, long long t, int newlen)
 {

@@ -70,42 +70,43 @@ static inline void slip_mac96(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t 
     hi += (uint32_t)(sum < p);
     acc = sum;
 }
-static inline uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
-static inline int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v > o) *p = v; return o; }
-static inline int32_t  slip_atomic_min_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v < o) *p = v; return o; }
-static inline int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
-static inline uint32_t slip_atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { uint32_t o = *p; if (o == expect) *p = v; return o; }
-static inline unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+static inline uint32_t slip_atomic_or_u32(uint32_t *p, uint32_t v) { emu::sync_addr(p); uint32_t o = *p; *p = o | v; return o; }
+static inline int32_t  slip_atomic_max_i32(int32_t *p, int32_t v) { emu::sync_addr(p); int32_t o = *p; if (v > o) *p = v; return o; }
+static inline int32_t  slip_atomic_min_i32(int32_t *p, int32_t v) { emu::sync_addr(p); int32_t o = *p; if (v < o) *p = v; return o; }
+static inline int32_t  slip_atomic_add_i32(int32_t *p, int32_t v) { emu::sync_addr(p); int32_t o = *p; *p = o + v; return o; }
+static inline uint32_t slip_atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { emu::sync_addr(p); uint32_t o = *p; if (o == expect) *p = v; return o; }
+static inline unsigned long long slip_atomic_add_u64(unsigned long long *p, unsigned long long v) { emu::sync_addr(p); unsigned long long o = *p; *p = o + v; return o; }
 static inline void slip_fence_block(void) {}
 static inline void slip_fence_device(void) {}
-/* agent-scope hand-off primitives (no-ops on the sequential emulator) */
-static inline void slip_vm_drain(void) {}
-static inline void slip_agent_release(void) {}
+/* agent-scope hand-off primitives (what they order only matters in the emulator's weak-store mode, fiber_emu.h: a drain /
+ * release empties the calling wave's store buffer; the hand-off store and the read-modify-write words do so first) */
+static inline void slip_vm_drain(void) { emu::drain(); }
+static inline void slip_agent_release(void) { emu::drain(); }
 static inline void slip_agent_acquire(void) {}
-static inline int32_t slip_agent_load_i32(const int32_t *p) { return *(volatile const int32_t *) p; }
-static inline void slip_agent_store_i32(int32_t *p, int32_t v) { *(volatile int32_t *) p = v; }
-static inline int32_t slip_agent_add_i32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
+static inline int32_t slip_agent_load_i32(const int32_t *p) { return (int32_t) emu::load(p, 4); }
+static inline void slip_agent_store_i32(int32_t *p, int32_t v) { emu::drain(); *(volatile int32_t *) p = v; }
+static inline int32_t slip_agent_add_i32(int32_t *p, int32_t v) { emu::sync_addr(p); int32_t o = *p; *p = o + v; return o; }
 static inline void slip_sleep(void) { emu::spin_yield(); }       /* a spin-wait iteration: let the other workgroups run */
 static inline void slip_sleep_short(void) { emu::spin_yield(); }
 static inline unsigned long long slip_clock(void) { return 0; }
 static inline unsigned long long slip_realtime(void) { return 0; }
-/* data other workgroups write / read during a launch (sc1 on the device; plain here: the emulator is sequentially consistent) */
-static inline uint32_t slip_ld_u32(const uint32_t *p) { return *(volatile const uint32_t *) p; }
-static inline int32_t  slip_ld_i32(const int32_t *p)  { return *(volatile const int32_t *) p; }
-static inline uint64_t slip_ld_u64(const uint64_t *p) { return *(volatile const uint64_t *) p; }
-static inline int64_t  slip_ld_i64(const int64_t *p)  { return *(volatile const int64_t *) p; }
-static inline void slip_st_u32(uint32_t *p, uint32_t v) { *(volatile uint32_t *) p = v; }
-static inline void slip_st_i32(int32_t *p, int32_t v)   { *(volatile int32_t *) p = v; }
-static inline void slip_st_u64(uint64_t *p, uint64_t v) { *(volatile uint64_t *) p = v; }
-static inline void slip_st_i64(int64_t *p, int64_t v)   { *(volatile int64_t *) p = v; }
+/* data other workgroups write / read during a launch (sc1 on the device): through the emulator's store buffers */
+static inline uint32_t slip_ld_u32(const uint32_t *p) { return (uint32_t) emu::load(p, 4); }
+static inline int32_t  slip_ld_i32(const int32_t *p)  { return (int32_t) emu::load(p, 4); }
+static inline uint64_t slip_ld_u64(const uint64_t *p) { return emu::load(p, 8); }
+static inline int64_t  slip_ld_i64(const int64_t *p)  { return (int64_t) emu::load(p, 8); }
+static inline void slip_st_u32(uint32_t *p, uint32_t v) { emu::store(p, v, 4); }
+static inline void slip_st_i32(int32_t *p, int32_t v)   { emu::store(p, (uint32_t) v, 4); }
+static inline void slip_st_u64(uint64_t *p, uint64_t v) { emu::store(p, v, 8); }
+static inline void slip_st_i64(int64_t *p, int64_t v)   { emu::store(p, (uint64_t) v, 8); }
 /* this workgroup's own global data (plain global accesses on the device) */
 static inline uint32_t slip_gld_u32(const uint32_t *p) { return *p; }
 static inline void slip_gst_u32(uint32_t *p, uint32_t v) { *p = v; }
-static inline int32_t slip_agent_max_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v > o) *p = v; return o; }
-static inline int32_t slip_agent_cas_i32(int32_t *p, int32_t expect, int32_t v) { int32_t o = *p; if (o == expect) *p = v; return o; }
-static inline int64_t slip_agent_min_i64(int64_t *p, int64_t v) { int64_t o = *p; if (v < o) *p = v; return o; }
-static inline unsigned long long slip_agent_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
-static inline unsigned long long slip_agent_max_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
+static inline int32_t slip_agent_max_i32(int32_t *p, int32_t v) { emu::sync_addr(p); int32_t o = *p; if (v > o) *p = v; return o; }
+static inline int32_t slip_agent_cas_i32(int32_t *p, int32_t expect, int32_t v) { emu::sync_addr(p); int32_t o = *p; if (o == expect) *p = v; return o; }
+static inline int64_t slip_agent_min_i64(int64_t *p, int64_t v) { emu::sync_addr(p); int64_t o = *p; if (v < o) *p = v; return o; }
+static inline unsigned long long slip_agent_add_u64(unsigned long long *p, unsigned long long v) { emu::sync_addr(p); unsigned long long o = *p; *p = o + v; return o; }
+static inline unsigned long long slip_agent_max_u64(unsigned long long *p, unsigned long long v) { emu::sync_addr(p); unsigned long long o = *p; if (v > o) *p = v; return o; }
 static inline int slip_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 static inline int slip_ctz32(uint32_t v) { return v ? __builtin_ctz(v) : 32; }
 static inline int slip_clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }

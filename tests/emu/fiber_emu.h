@@ -7,8 +7,19 @@
  * to completion on one OS thread.  The order in which workgroups get the processor is a seeded
  * pseudo-random interleaving (emu::set_seed), which lets the tests shake the hand-off logic.
  * All 64 lanes of a wave must reach the same call site (checked): exactly the wave-uniform
- * control flow the real kernel needs.  Memory is sequentially consistent here: cache-visibility
+ * control flow the real kernel needs.  Memory is sequentially consistent by default: cache-visibility
  * bugs (missing sc1 / release) are NOT found by this emulator, logic and ordering bugs are.
+ *
+ * WEAK-STORE MODE (emu::set_weak(1)): the stores other workgroups are meant to see (the slip_st_* /
+ * sc1 accessors of wave_shim.h) do not reach memory when they are issued.  Each WAVE keeps them in a buffer; an entry
+ * lands at a pseudo-random later moment, in any order except that stores of one wave to one address keep theirs (that is
+ * all the hardware promises for write-through stores in flight).  The issuing wave sees its own pending stores (same-address
+ * ordering within a wave), nobody else does -- not even the other waves of its workgroup.  A wave's buffer is emptied by what
+ * empties it on the device: slip_vm_drain (s_waitcnt vmcnt(0)), slip_agent_release, a workgroup barrier (__syncthreads
+ * waits for the wave's memory operations first), and the agent-scope store/atomics used as hand-off words.  Plain stores
+ * (bulk data written before a release fence) are NOT modelled: they stay immediately visible, which errs on the quiet
+ * side.  What the mode finds: a hand-off word that can overtake the data it announces (a missing drain), and two waves
+ * writing one word with the order left to chance -- the two protocol races of rounds 2 and 3.
  * Nothing here is part of the product.
  */
 #ifndef FIBER_EMU_H
@@ -28,11 +39,13 @@ extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const voi
 
 namespace emu {
 
+struct Pending { void *addr; uint64_t val; int size; };
 struct WaveCtx {
     uint64_t vals[64], out[64];
     int site[64];
     int arrived = 0;
     unsigned gen = 0;
+    std::vector<Pending> pending;        /* weak-store mode: this wave's stores that have not landed yet, in program order */
 };
 
 struct Block {
@@ -53,6 +66,8 @@ struct State {
     const void *sched_stack = nullptr; size_t sched_stack_size = 0;
     unsigned long progress = 0;          /* bumped whenever a collective / barrier completes or a thread ends */
     unsigned long long rng = 0x9E3779B97F4A7C15ull;
+    int weak = 0;                        /* weak-store mode */
+    unsigned long pending_total = 0;
     std::function<void()> body;
 };
 
@@ -60,6 +75,79 @@ inline State &S() { static State s; return s; }
 
 inline void set_seed(unsigned long long seed) { S().rng = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull; }
 inline unsigned rnd() { State &s = S(); s.rng ^= s.rng << 13; s.rng ^= s.rng >> 7; s.rng ^= s.rng << 17; return (unsigned)(s.rng >> 32); }
+
+inline void set_weak(int on) { S().weak = on; }
+inline void poke(void *addr, uint64_t v, int size)
+{
+    if (size == 4) *(volatile uint32_t *) addr = (uint32_t) v; else *(volatile uint64_t *) addr = v;
+}
+/* a store other workgroups are meant to see */
+inline void store(void *addr, uint64_t v, int size)
+{
+    State &s = S();
+    if (!s.weak) { poke(addr, v, size); return; }
+    s.blocks[s.block].waves[s.cur >> 6].pending.push_back(Pending{addr, v, size});
+    s.pending_total++;
+}
+/* a load of such data: memory, or this wave's own newest pending store to the address */
+inline uint64_t load(const void *addr, int size)
+{
+    State &s = S();
+    if (s.weak) {
+        const std::vector<Pending> &p = s.blocks[s.block].waves[s.cur >> 6].pending;
+        for (size_t i = p.size(); i-- > 0;) {
+            if (p[i].addr == addr && p[i].size == size) return p[i].val;
+            /* a 4-byte read of half of a pending 8-byte store (and the reverse) is not forwarded: the code never does that
+             * with data in flight, and memory order of mixed sizes is the hardware's business */
+        }
+    }
+    return size == 4 ? (uint64_t) *(volatile const uint32_t *) addr : *(volatile const uint64_t *) addr;
+}
+/* everything this wave has issued reaches memory, in program order (s_waitcnt vmcnt(0) / a release / a barrier) */
+inline void drain()
+{
+    State &s = S();
+    if (!s.weak) return;
+    std::vector<Pending> &p = s.blocks[s.block].waves[s.cur >> 6].pending;
+    for (const Pending &e : p) poke(e.addr, e.val, e.size);
+    s.pending_total -= p.size();
+    p.clear();
+}
+/* a read-modify-write of a word: this wave's own pending stores to it land first (same-address order within a wave) */
+inline void sync_addr(const void *addr)
+{
+    State &s = S();
+    if (!s.weak) return;
+    std::vector<Pending> &p = s.blocks[s.block].waves[s.cur >> 6].pending;
+    for (size_t i = 0; i < p.size();) {
+        if (p[i].addr == addr) { poke(p[i].addr, p[i].val, p[i].size); p.erase(p.begin() + (long) i); s.pending_total--; }
+        else i++;
+    }
+}
+/* a few pending stores of the grid land, in any order that keeps one wave's stores to one address in theirs */
+inline void land_some()
+{
+    State &s = S();
+    if (!s.weak || !s.pending_total) return;
+    const int tries = 1 + (int)(rnd() % 6u);
+    for (int t = 0; t < tries && s.pending_total; t++) {
+        Block &b = s.blocks[rnd() % (unsigned) s.nblocks];
+        if (b.waves.empty()) continue;
+        std::vector<Pending> &p = b.waves[rnd() % (unsigned) b.waves.size()].pending;
+        if (p.empty()) continue;
+        size_t pick = rnd() % (unsigned) p.size();
+        for (size_t i = 0; i < pick; i++) if (p[i].addr == p[pick].addr) { pick = i; break; }     /* the oldest store to that word first */
+        poke(p[pick].addr, p[pick].val, p[pick].size);
+        p.erase(p.begin() + (long) pick);
+        s.pending_total--;
+    }
+}
+inline void land_all()
+{
+    State &s = S();
+    for (Block &b : s.blocks) for (WaveCtx &w : b.waves) { for (const Pending &e : w.pending) poke(e.addr, e.val, e.size); w.pending.clear(); }
+    s.pending_total = 0;
+}
 
 inline int tid() { return S().cur; }
 inline int nthreads() { return S().nthreads; }
@@ -133,6 +221,7 @@ inline void block_sync(int site)
     State &s = S();
     Block &b = s.blocks[s.block];
     unsigned g = b.bar_gen;
+    drain();                             /* __syncthreads waits for the wave's outstanding memory operations first */
     b.last_site[s.cur] = -site;
     if (b.bar_arrived == 0) b.bar_site = site;
     else if (b.bar_site != site) die("threads at different barriers, lines", b.bar_site, site);
@@ -217,9 +306,10 @@ inline void launch(int nblocks, int nthreads_, std::function<void()> body, size_
             while (s.blocks[b].remaining > 0) {
                 if (s.progress != seen) { seen = s.progress; idle = 0; }
                 else if (++idle > 64) report_deadlock();
-                run_pass(b);
+                run_pass(b); land_some();
             }
         }
+        land_all();
         return;
     }
     for (int b = 0; b < nblocks; b++) arm(b);
@@ -232,9 +322,10 @@ inline void launch(int nblocks, int nthreads_, std::function<void()> body, size_
         int b = (int)(rnd() % (unsigned) nblocks);
         while (s.blocks[b].remaining == 0) b = (b + 1) % nblocks;
         const int passes = 1 + (int)(rnd() % 4u);
-        for (int p = 0; p < passes && s.blocks[b].remaining > 0; p++) run_pass(b);
+        for (int p = 0; p < passes && s.blocks[b].remaining > 0; p++) { run_pass(b); land_some(); }
         if (s.blocks[b].remaining == 0) live--;
     }
+    land_all();
 }
 
 } /* namespace emu */
