@@ -92,18 +92,34 @@ typedef struct SlipState {
 } SlipState;
 
 /* immutable during a launch: passed by value, copied to LDS, private fields set per worker there */
+/* A pointer to data that OTHER workgroups read or write during a launch: it has no operator[] and no
+ * operator*, so a plain dereference -- a load the compiler may keep in a register or serve from a stale line, a store that
+ * never leaves the L1 -- does not compile.  at(i) is the address for the accessors of wave_shim.h (slip_ld_* / slip_st_*:
+ * sc1, agent scope; the atomics); fixed(i) is a plain read for launches in which nobody writes the array (the solves).
+ * The host side reaches the raw pointer as p_ (allocation, copies, kernel arguments). */
+#if defined(SLIP_EMULATE)
+#define SLIP_HD
+#else
+#define SLIP_HD __host__ __device__ __forceinline__
+#endif
+template <class T> struct slip_shared {
+    T *p_;
+    SLIP_HD T *at(int64_t i = 0) const { return p_ + i; }
+    SLIP_HD T fixed(int64_t i) const { return p_[i]; }
+};
+
 typedef struct SlipParams {
     int32_t n, pivot_scheme, limb_cap, tol_mode;    /* tol_mode 0: tol <= 0          */
     uint64_t tol_m; int32_t tol_e, k_stop;          /* tol = tol_m * 2^tol_e         */
     const int64_t *Ap; const int32_t *Ai; const int32_t *Alen; const int64_t *Aoff;
     const uint64_t *Alimbs; const int32_t *q;
-    int32_t *pinv, *row_perm;                       /* shared: swapped at stage 1 of every column */
+    slip_shared<int32_t> pinv, row_perm;            /* shared: swapped at stage 1 of every column */
     SlipRow *xrow; uint32_t *xd;                    /* PRIVATE per worker (the kernel offsets the bases): row i's digits at xd[i*xcap] */
-    SlipPiv *piv; uint32_t *invd;                   /* shared: pivot p's inverse at invd[p*invcap] */
+    slip_shared<SlipPiv> piv; slip_shared<uint32_t> invd;   /* shared: pivot p's inverse at invd[p*invcap] */
     int32_t xcap, invcap, wcap, bm_words;
     int64_t *Lp, *Lo; int32_t *Li; SlipEnt *Le; uint64_t *Llimbs; int64_t Lcap_nz, Lcap_nl;   /* Lo: limb offset of a column's first entry */
     int64_t *Up, *Uo; int32_t *Ui; SlipEnt *Ue; uint64_t *Ulimbs; int64_t Ucap_nz, Ucap_nl;
-    int32_t *Lready;                                /* shared: column c's L entries and limbs are published (stage 2)  */
+    slip_shared<int32_t> Lready;                    /* shared: column c's L entries and limbs are published (stage 2)  */
     int32_t *pat;                                   /* PRIVATE: pattern of the column (positions, ascending) when it exceeds the LDS cap */
     int32_t *rlist;                                 /* PRIVATE: rows of the pattern in discovery order                  */
     int32_t *rpos;                                  /* PRIVATE: their positions at commit time (patterns beyond the LDS cap) */
@@ -116,9 +132,9 @@ typedef struct SlipParams {
     int32_t committer;                              /* 1: block 0 of the launch is the committer (ref_lu_pipe_commit.h), the others are column workers */
     int32_t quiet_neighbours;                       /* workers on CUs within this distance of the committer's stand aside (they share its instruction cache) */
     int32_t engine;                                 /* 1: the committer keeps a mirror of pinv in LDS and runs the chain engine (full packages of short one-limb columns) */
-    uint32_t *pkg;                                  /* shared: one package slot per worker (SLIP_PKG_WORDS words each)      */
-    uint32_t *jobs; int32_t farm, in_factor; SlipState *st;     /* in_factor: a factorisation launch (the stop word names columns) */            /* shared: one job slot per worker (SLIP_JOB_WORDS words): a long update queue other workers help with */
-    int32_t *sw_row, *sw_pos;                       /* shared: the swap log -- column c's pivot changed places with row sw_row[c] (= row_perm[c] before), which moved to position sw_pos[c] (= the pivot row's position before) */
+    slip_shared<uint32_t> pkg;                      /* shared: one package slot per worker (SLIP_PKG_WORDS words each)      */
+    slip_shared<uint32_t> jobs; int32_t farm, in_factor; SlipState *st;     /* in_factor: a factorisation launch (the stop word names columns) */            /* shared: one job slot per worker (SLIP_JOB_WORDS words): a long update queue other workers help with */
+    slip_shared<int32_t> sw_row, sw_pos;            /* shared: the swap log -- column c's pivot changed places with row sw_row[c] (= row_perm[c] before), which moved to position sw_pos[c] (= the pivot row's position before) */
     int64_t priv_rows;                              /* rows per worker of the private arrays (= n)                      */
     int32_t *dbg;
 } SlipParams;
@@ -193,7 +209,7 @@ enum { SV_ERR = 0, SV_CNT0 = 1 /* 3 rotating work counters */, SV_MAXDIG = 4, SV
 #define SLIP_MIRROR_MAX  16384    /* the chain engine keeps pinv in LDS (16-bit): matrices up to this dimension */
 #define SLIP_MBOX_HDR    32       /* a worker's mailbox, behind the package slots: the outcome words, then (full packages) the rows handed back */
 #define SLIP_MBOX_WORDS  (SLIP_MBOX_HDR + 4 * SLIP_ENG_ROWS)
-#define SLIP_PKG_OUT     0        /* the outcome words, as offsets into the exporting worker's MAILBOX (P.pkg + nworkers * SLIP_PKG_WORDS + worker * SLIP_MBOX_WORDS) */
+#define SLIP_PKG_OUT     0        /* the outcome words, as offsets into the exporting worker's MAILBOX (P.pkg.at() + nworkers * SLIP_PKG_WORDS + worker * SLIP_MBOX_WORDS) */
 #define SLIP_PKG_CAND    64       /* 6 words per candidate: table index, value (2), aux, position, version */
 #define SLIP_PKG_ROWS    160      /* kind 0: the rows of the pattern; kind 1: four arrays of SLIP_PKG_FULLMAX words: row, value (2), sign | history */
 #define SLIP_PKG_WORDS   704
@@ -485,23 +501,23 @@ SLIP_DEV void slip_store_small(const SlipParams &P, int i, slip_u128 mag, int sg
  * write-back) after the inverse cache has been extended. */
 SLIP_DEV int slip_ensure_inv(const SlipParams &P, int p, int want, dig_t *b0, dig_t *b1, dig_t *b2)
 {
-    int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(&P.piv[p]));
+    int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(P.piv.at(p)));
     slip_agent_acquire();                     /* digits below `have` (and, if enough, all we need) are readable now */
     if (have >= want) return 0;
     if (want > P.invcap || want > P.wcap) return 1;
     int target = 2 * have > want ? 2 * have : want;
     if (target > P.invcap) target = P.invcap;
     if (target > P.wcap) target = P.wcap;
-    const SlipPiv pv = slip_ld_piv(&P.piv[p]);
+    const SlipPiv pv = slip_ld_piv(P.piv.at(p));
     const int ld = slip_abs(pv.len), z = pv.ctz;
     int lodd = ld - (z >> 5);
     if (lodd > target) lodd = target;
     wb_copy_shr(b0, slip_piv_digits(P, pv), ld, z, lodd);
-    dig_t *inv = P.invd + (int64_t) p * P.invcap;
+    dig_t *inv = P.invd.at() + (int64_t) p * P.invcap;
     wb_inv_extend(inv, have, target, b0, lodd, b1, b2);
     slip_vm_drain();
     slip_agent_release();
-    if (slip_lane() == 0) slip_agent_max_i32(&P.piv[p].invlen, target);
+    if (slip_lane() == 0) slip_agent_max_i32(&P.piv.at(p)->invlen, target);
     slip_wave_sync();
     return 0;
 }
@@ -547,19 +563,19 @@ template <int D> SLIP_DEV WR<D> slip_piv_odd_reg(const SlipParams &P, const Slip
 /* cached inverse of pivot p's odd part to `want` digits, register Newton; b0: scratch for wide shifts */
 template <int D> SLIP_DEV int slip_ensure_inv_reg(const SlipParams &P, int p, int want, dig_t *b0)
 {
-    int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(&P.piv[p]));
+    int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(P.piv.at(p)));
     if (have >= want) return 0;
     if (want > P.invcap) return 1;
     int target = 2 * have > want ? 2 * have : want;
     if (target > P.invcap) target = P.invcap;
     if (target > 64 * D) target = 64 * D;
-    const SlipPiv pv = slip_ld_piv(&P.piv[p]);
+    const SlipPiv pv = slip_ld_piv(P.piv.at(p));
     const WR<D> dodd = slip_piv_odd_reg<D>(P, pv, b0);
-    dig_t *inv = P.invd + (int64_t) p * P.invcap;
+    dig_t *inv = P.invd.at() + (int64_t) p * P.invcap;
     WR<D> V = wr_inv_extend<D>(wr_load_s<D>(inv, have), have, target, dodd);
     wr_store_s<D>(inv, V, target);
     slip_vm_drain();
-    if (slip_lane() == 0) slip_agent_max_i32(&P.piv[p].invlen, target);
+    if (slip_lane() == 0) slip_agent_max_i32(&P.piv.at(p)->invlen, target);
     slip_wave_sync();
     return 0;
 }
@@ -579,11 +595,11 @@ template <int D> SLIP_DEV int slip_ensure_inv_reg(const SlipParams &P, int p, in
 #endif
 template <int D> SLIP_DEV int slip_div_piv_reg(const SlipParams &P, WR<D> &Y, int W, int pd, const SlipPiv &d, dig_t *b0)
 {
-    const int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(&P.piv[pd]));
+    const int have = (int) slip_bcast0_u32((uint32_t) slip_piv_invlen(P.piv.at(pd)));
     if (have < W) {
-        const uint32_t asked = slip_bcast0_u32(slip_ld_u32((const uint32_t *) &P.piv[pd].pad));
+        const uint32_t asked = slip_bcast0_u32(slip_ld_u32((const uint32_t *) &P.piv.at(pd)->pad));
         if (asked < (uint32_t) SLIP_INV_DEMAND) {
-            if (slip_lane() == 0) (void) slip_agent_add_i32((int32_t *) &P.piv[pd].pad, 1)       /* (result unused: the no-return form) */;
+            if (slip_lane() == 0) (void) slip_agent_add_i32((int32_t *) &P.piv.at(pd)->pad, 1)       /* (result unused: the no-return form) */;
             const WR<D> dodd = slip_piv_odd_reg<D>(P, d, b0);
             Y = wr_div_hensel<D>(Y, W, dodd);
             return 0;
@@ -591,7 +607,7 @@ template <int D> SLIP_DEV int slip_div_piv_reg(const SlipParams &P, WR<D> &Y, in
         const int e = slip_ensure_inv_reg<D>(P, pd, W, b0);
         if (e) return e;
     }
-    const WR<D> I = wr_load_s<D>(P.invd + (int64_t) pd * P.invcap, W);
+    const WR<D> I = wr_load_s<D>(P.invd.at() + (int64_t) pd * P.invcap, W);
     Y = wr_mask<D>(wr_mul<D>(I, W, Y), W);
     return 0;
 }
@@ -631,11 +647,11 @@ template <int D> SLIP_DEV int slip_history_wave_reg(const SlipParams &P, int r, 
     SlipRow xr = P.xrow[r];
     if (newh != SLIP_KEEP_H) xr.h = newh;
     const int lx = slip_abs(xr.len);
-    const SlipPiv m = slip_ld_piv(&P.piv[pm]);
+    const SlipPiv m = slip_ld_piv(P.piv.at(pm));
     const int lm = slip_abs(m.len);
     int sign = slip_sgn(xr.len) * slip_sgn(m.len);
     if (pd >= 0) {
-        const SlipPiv d = slip_ld_piv(&P.piv[pd]);
+        const SlipPiv d = slip_ld_piv(P.piv.at(pd));
         const int W = (xr.bits + m.bits - d.bits + 1 + 31) >> 5;
         if (W > P.invcap) return 1;
         WR<D> X = wr_load_g<D>(P.xd + (int64_t) r * P.xcap, lx), M = wr_load_s<D>(slip_piv_digits(P, m), lm);
@@ -672,9 +688,9 @@ template <int D> SLIP_DEV int slip_cand_compare_reg(const SlipParams &P, int r, 
 {
     const SlipRow xr = P.xrow[r];
     const int lx = slip_abs(xr.len);
-    const SlipPiv m = slip_ld_piv(&P.piv[pm]);
+    const SlipPiv m = slip_ld_piv(P.piv.at(pm));
     const int lm = slip_abs(m.len);
-    const SlipPiv d = slip_ld_piv(&P.piv[pd]);
+    const SlipPiv d = slip_ld_piv(P.piv.at(pd));
     const int W = (xr.bits + m.bits - d.bits + 1 + 31) >> 5;
     if (W > P.invcap) return 2;
     const WR<D> M = wr_load_s<D>(slip_piv_digits(P, m), lm);
@@ -696,7 +712,7 @@ SLIP_DEVN int slip_cand_compare_out(const SlipParams *Pg, int r, int pm, int pd,
 {
     const SlipParams &P = *Pg;
     const SlipRow xr = P.xrow[r];
-    const SlipPiv m = slip_ld_piv(&P.piv[pm]), d = slip_ld_piv(&P.piv[pd]);
+    const SlipPiv m = slip_ld_piv(P.piv.at(pm)), d = slip_ld_piv(P.piv.at(pd));
     /* widths: the shifted product x * rho[pm] and a * rho[pm] must fit the registers */
     const int Wn = ((xr.bits + m.bits + 31) >> 5) + 1, Wa = slip_abs(m.len) + 2;
     const int Wmax = Wn > Wa ? Wn : Wa;
@@ -713,14 +729,14 @@ SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t
     if (newh != SLIP_KEEP_H) xr.h = newh;             /* the history tag the updated row carries */
     const int lx = slip_abs(xr.len);
     const dig_t *X = P.xd + (int64_t) r * P.xcap;
-    const SlipPiv m = slip_ld_piv(&P.piv[pm]);
+    const SlipPiv m = slip_ld_piv(P.piv.at(pm));
     const int lm = slip_abs(m.len);
     int sign = slip_sgn(xr.len) * slip_sgn(m.len);
     int bq = xr.bits + m.bits;
     {
         /* widths: W digits of result; the shifted product needs W + ceil(ctz/32) */
         int Wn = (bq + 31) >> 5;
-        if (pd >= 0) { const SlipPiv d0 = slip_ld_piv(&P.piv[pd]); Wn = ((bq - d0.bits + 1 + 31) >> 5) + ((d0.ctz + 31) >> 5); }
+        if (pd >= 0) { const SlipPiv d0 = slip_ld_piv(P.piv.at(pd)); Wn = ((bq - d0.bits + 1 + 31) >> 5) + ((d0.ctz + 31) >> 5); }
         if (Wn > P.wcap) return 1;
         if (Wn <= 64)  return slip_history_wave_reg<1>(P, r, pm, pd, b0, newh);
         if (Wn <= 128) return slip_history_wave_reg<2>(P, r, pm, pd, b0, newh);
@@ -735,14 +751,14 @@ SLIP_DEV int slip_history_wave(const SlipParams &P, int r, int pm, int pd, dig_t
         wb_mul_lo(b0, X, lx, slip_piv_digits(P, m), lm, W);
         return slip_store_x(P, r, b0, W, sign, xr.h, xr.tag);
     }
-    const SlipPiv d = slip_ld_piv(&P.piv[pd]);
+    const SlipPiv d = slip_ld_piv(P.piv.at(pd));
     bq -= d.bits - 1;
     const int W = (bq + 31) >> 5, zh = d.ctz, W2 = W + ((zh + 31) >> 5);
     if (W2 > P.wcap) return 1;
     { const int e = slip_ensure_inv(P, pd, W, b0, b1, b2); if (e) return e; }
     wb_mul_lo(b0, X, lx, slip_piv_digits(P, m), lm, W2);
     wb_copy_shr(b1, b0, W2, zh, W);
-    wb_mul_lo(b2, b1, W, P.invd + (int64_t) pd * P.invcap, W, W);
+    wb_mul_lo(b2, b1, W, P.invd.at() + (int64_t) pd * P.invcap, W, W);
     return slip_store_x(P, r, b2, W, sign * slip_sgn(d.len), xr.h, xr.tag);
 }
 
@@ -759,11 +775,11 @@ SLIP_DEV SlipIpgePlan slip_ipge_plan(const SlipParams &P, const SlipRow &xi, con
     const int lx = slip_abs(xi.len), hi = xi.h, br = R.bits;
     pl.has_d = jn >= 1;
     int bd = 0, zd = 0;
-    if (pl.has_d) { const SlipPiv Dd = slip_ld_piv(&P.piv[jn - 1]); bd = Dd.bits; zd = Dd.ctz; }
+    if (pl.has_d) { const SlipPiv Dd = slip_ld_piv(P.piv.at(jn - 1)); bd = Dd.bits; zd = Dd.ctz; }
     pl.hist = lx != 0 && pl.has_d && hi < jn - 1;
     pl.hdiv = pl.hist && hi > -1;
     int bh = 0, zh = 0;
-    if (pl.hdiv) { const SlipPiv H = slip_ld_piv(&P.piv[hi]); bh = H.bits; zh = H.ctz; }
+    if (pl.hdiv) { const SlipPiv H = slip_ld_piv(P.piv.at(hi)); bh = H.bits; zh = H.ctz; }
     const int bxp = !lx ? 0 : (!pl.hist ? xi.bits : (pl.hdiv ? xi.bits + bd - bh + 1 : xi.bits + bd));
     const int b1b = lx ? bxp + br : 0, b2b = le.bits + xj.bits;
     const int bnum = (b1b > b2b ? b1b : b2b) + 1;
@@ -781,7 +797,7 @@ template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int
     const int has_d = jn >= 1;
     const int lx = slip_abs(xi.len);
     SlipPiv Dv = slip_piv_none();
-    if (has_d) Dv = slip_ld_piv(&P.piv[jn - 1]);
+    if (has_d) Dv = slip_ld_piv(P.piv.at(jn - 1));
     if (hdiv && W1 > P.invcap) return 1;
     if (has_d) { const int e = slip_ensure_inv_reg<D>(P, jn - 1, W, b0); if (e) return e; }
     const int CAP = 64 * D;
@@ -801,7 +817,7 @@ template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int
             s1 *= slip_sgn(Dv.len);
             ly = W1;
             if (hdiv) {
-                const SlipPiv H = slip_ld_piv(&P.piv[xi.h]);
+                const SlipPiv H = slip_ld_piv(P.piv.at(xi.h));
                 Y = wr_mask<D>(wr_shr<D>(Y, H.ctz, b0), W1);
                 { const int e = slip_div_piv_reg<D>(P, Y, W1, xi.h, H, b0); if (e) return e; }
                 s1 *= slip_sgn(H.len);
@@ -824,7 +840,7 @@ template <int D> SLIP_DEV int slip_ipge_wave_reg(const SlipParams &P, int i, int
     T = wr_mask<D>(T, W1);
     if (has_d) {
         T = wr_mask<D>(wr_shr<D>(T, Dv.ctz, b0), W);
-        WR<D> ID = wr_load_s<D>(P.invd + (int64_t)(jn - 1) * P.invcap, W);
+        WR<D> ID = wr_load_s<D>(P.invd.at() + (int64_t)(jn - 1) * P.invcap, W);
         T = wr_mask<D>(wr_mul<D>(ID, W, T), W);
         sT *= slip_sgn(Dv.len);
     }
@@ -837,7 +853,7 @@ SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m
 {
     const SlipRow xi = P.xrow[i], xj = P.xrow[j];
     const SlipEnt le = slip_ld_ent(&P.Le[m]);
-    const SlipPiv R = slip_ld_piv(&P.piv[jn]);
+    const SlipPiv R = slip_ld_piv(P.piv.at(jn));
     const int lx = slip_abs(xi.len), sx = slip_sgn(xi.len);
     const dig_t *X = P.xd + (int64_t) i * P.xcap;
     const int lr = slip_abs(R.len), sr = slip_sgn(R.len);
@@ -855,10 +871,10 @@ SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m
     if (W2 <= 192) return slip_ipge_wave_reg<3>(P, i, j, jn, m, b0, xi, xj, le, R, W, W1, hist, hdiv);
     if (W2 <= 256) return slip_ipge_wave_reg<4>(P, i, j, jn, m, b0, xi, xj, le, R, W, W1, hist, hdiv);
     SlipPiv D = slip_piv_none();
-    if (has_d) D = slip_ld_piv(&P.piv[jn - 1]);
+    if (has_d) D = slip_ld_piv(P.piv.at(jn - 1));
     const int ld = slip_abs(D.len), sd = has_d ? slip_sgn(D.len) : 1, zd = D.ctz;
     int zh = 0, sh = 1;
-    if (hdiv) { const SlipPiv H = slip_ld_piv(&P.piv[hi]); zh = H.ctz; sh = slip_sgn(H.len); }
+    if (hdiv) { const SlipPiv H = slip_ld_piv(P.piv.at(hi)); zh = H.ctz; sh = slip_sgn(H.len); }
     if (hdiv) { const int e = slip_ensure_inv(P, hi, W1, b0, b1, b2); if (e) return e; }
     if (has_d) { const int e = slip_ensure_inv(P, jn - 1, W, b0, b1, b2); if (e) return e; }
     slip_agent_acquire();                      /* wide operands (see slip_ensure_inv): plain loads from here on */
@@ -875,7 +891,7 @@ SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m
     } else {
         wb_mul_lo(b0, X, lx, slip_piv_digits(P, D), ld, W2);
         wb_copy_shr(b1, b0, W2, zh, W1);
-        wb_mul_lo(b0, b1, W1, P.invd + (int64_t) hi * P.invcap, W1, W1);
+        wb_mul_lo(b0, b1, W1, P.invd.at() + (int64_t) hi * P.invcap, W1, W1);
         wb_mul_lo(b1, b0, W1, slip_piv_digits(P, R), lr, W1);
         s1 *= sd * sh;
     }
@@ -891,7 +907,7 @@ SLIP_DEV int slip_ipge_wave(const SlipParams &P, int i, int j, int jn, int64_t m
     dig_t *Q = b1;
     if (has_d) {
         wb_copy_shr(b0, b1, W1, zd, W);
-        wb_mul_lo(b2, b0, W, P.invd + (int64_t)(jn - 1) * P.invcap, W, W);
+        wb_mul_lo(b2, b0, W, P.invd.at() + (int64_t)(jn - 1) * P.invcap, W, W);
         Q = b2; sT *= sd;
     }
     /* two's complement -> sign-magnitude */
@@ -924,7 +940,7 @@ SLIP_DEV int slip_history_small(const SlipParams &P, const SlipRow &xr, uint64_t
     slip_u128 y = (slip_u128) xv * m.lo;
     int s = slip_sgn(xr.len) * slip_sgn(m.len);
     if (pd >= 0) {
-        const SlipPiv d = slip_ld_piv(&P.piv[pd]);
+        const SlipPiv d = slip_ld_piv(P.piv.at(pd));
         if (slip_abs(d.len) > 2) return 0;
         y = slip_divexact128(y, d.lo, d.ctz, d.inv64);
         s *= slip_sgn(d.len);
@@ -1085,14 +1101,14 @@ SLIP_DEV int slip_divexact_wave(const SlipParams &P, int r, int p, dig_t *b0, di
 {
     const SlipRow xr = P.xrow[r];
     const int lx = slip_abs(xr.len);
-    const SlipPiv d = slip_ld_piv(&P.piv[p]);
+    const SlipPiv d = slip_ld_piv(P.piv.at(p));
     const int bq = xr.bits - d.bits + 1;
     const int W = bq > 0 ? (bq + 31) >> 5 : 1, zh = d.ctz, W2 = W + ((zh + 31) >> 5);
     if (W2 > P.wcap) return 1;
     { const int e = slip_ensure_inv_any(P, p, W, b0, b1, b2); if (e) return e; }
     slip_agent_acquire();
     wb_copy_shr(b1, P.xd + (int64_t) r * P.xcap, lx, zh, W);
-    wb_mul_lo(b2, b1, W, P.invd + (int64_t) p * P.invcap, W, W);
+    wb_mul_lo(b2, b1, W, P.invd.at() + (int64_t) p * P.invcap, W, W);
     return slip_store_x(P, r, b2, W, slip_sgn(xr.len) * slip_sgn(d.len), xr.h, xr.tag);
 }
 
@@ -1225,7 +1241,7 @@ SLIP_DEV int slip_farm_peek(const SlipParams &P, SlipState *st, int urgent_only 
         int h = slip_ld_i32(&st->farm_hint[(P.worker + q) & 7]);
         if (h < 0) { if (urgent_only) continue; h = -h; }
         if (h <= 0 || h - 1 == P.worker || h > P.nworkers) continue;
-        if (slip_ld_u32(P.jobs + (int64_t)(h - 1) * SLIP_JOB_WORDS) & 1u) return h;
+        if (slip_ld_u32(P.jobs.at() + (int64_t)(h - 1) * SLIP_JOB_WORDS) & 1u) return h;
     }
     return 0;
 }
@@ -1234,7 +1250,7 @@ SLIP_DEV int slip_farm_peek(const SlipParams &P, SlipState *st, int urgent_only 
 SLIP_DEV void slip_farm_help(const SlipParams &P, SlipState *st, uint32_t *lds, int slot, dig_t *b0, dig_t *b1, dig_t *b2)
 {
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
-    uint32_t *jb = P.jobs + (int64_t) slot * SLIP_JOB_WORDS;
+    uint32_t *jb = P.jobs.at() + (int64_t) slot * SLIP_JOB_WORDS;
     (void) st;
     slip_block_sync();
     if (slip_tid() == 0) {
@@ -1281,13 +1297,13 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
         /* kind 2: the rows of a committed column that still need their division (its readers wait for its stage 2).  The
          * protocol carries them and a 700-row column of the C4 window then takes 0.35 ms instead of 1.5 -- but the window as a
          * whole got slower (median 6.37 against 6.06 ms over 30 runs: every helper costs its XCD an L2 invalidate), so: off */
-        const int lr = slip_limbs(slip_ld_piv(&P.piv[kind == 1 ? jn : k - 1]).len);
+        const int lr = slip_limbs(slip_ld_piv(P.piv.at(kind == 1 ? jn : k - 1)).len);
         /* the queue alone takes about nq * 8 lr^2 / waves cycles; the frontier moves a column every few microseconds */
         const int64_t cost = (int64_t) nq * lr * lr;
         if (cost >= (kind == 2 ? (int64_t) SLIP_FARM_KIND2_COST : (int64_t) SLIP_FARM_MIN_COST) && (kind == 2 || SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
             /* a long queue of long updates: open it to the workers that are waiting */
             const int tid = slip_tid(), T = slip_nthreads();
-            uint32_t *jb = P.jobs + (int64_t) P.worker * SLIP_JOB_WORDS;
+            uint32_t *jb = P.jobs.at() + (int64_t) P.worker * SLIP_JOB_WORDS;
             for (int c = tid; c < (kind == 1 ? 2 * nq : nq); c += T) slip_st_u32(jb + 32 + c, wl[c]);
             if (tid == 0) {
                 slip_st_u32(jb + 2, (uint32_t) kind); slip_st_u32(jb + 3, (uint32_t) j); slip_st_u32(jb + 4, (uint32_t) jn); slip_st_u32(jb + 5, (uint32_t) k);

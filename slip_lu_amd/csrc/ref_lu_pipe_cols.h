@@ -68,7 +68,7 @@ SLIP_DEV int slip_advance_ready(const SlipParams &P, SlipState *st)
 {
     int f2 = slip_agent_add_i32(&st->F2, 0);
     int pr_; const int F = slip_ld_frontier(st, &pr_);
-    while (f2 < F && slip_agent_add_i32(&P.Lready[f2], 0) != 0) {
+    while (f2 < F && slip_agent_add_i32(P.Lready.at(f2), 0) != 0) {
         const int seen = slip_agent_cas_i32(&st->F2, f2, f2 + 1);
         f2 = seen == f2 ? f2 + 1 : seen;
     }
@@ -88,7 +88,7 @@ SLIP_DEV int slip_wait_ready(const SlipParams &P, SlipState *st, uint32_t *lds, 
         unsigned long long spins = 0;
         for (;;) {
             const int f2 = slip_advance_ready(P, st);
-            if (f2 >= need || slip_agent_add_i32(&P.Lready[need - 1], 0) != 0) { res = f2; break; }
+            if (f2 >= need || slip_agent_add_i32(P.Lready.at(need - 1), 0) != 0) { res = f2; break; }
             if ((int)(slip_ld_i64(&st->stop) & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             slip_sleep_short();
             if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 2; st->dbg_k = sv[SV_K]; st->dbg_a = need; st->dbg_b = f2; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
@@ -160,7 +160,7 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
     /* (a worker that has just seen a multi-limb pivot does not try for the next 64 columns: the values only grow) */
     const bool want_full = P.engine && Fl >= 1 && nrows <= SLIP_TAB_CAP - SLIP_ENG_ROWS && !(sv[SV_NOENG] > 0 && k - sv[SV_NOENG] < 64);
     SlipPiv Mf = slip_piv_none();
-    if (want_full) Mf = slip_ld_piv(&P.piv[Fl - 1]);
+    if (want_full) Mf = slip_ld_piv(P.piv.at(Fl - 1));
     const bool mf_small = want_full && slip_abs(Mf.len) <= 2;
     slip_block_sync();
     if (want_full && !mf_small && tid == 0) sv[SV_NOENG] = k;
@@ -173,7 +173,7 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
         int cls = 0, c = 0, isS = 0, r = 0, isU = 0, isNP = 0; uint32_t asgn = 0;
         if (t < nrows) {
             r = (int) f_row[t];
-            const int pos = slip_ld_i32(&P.pinv[r]);
+            const int pos = slip_ld_i32(P.pinv.at(r));
             const SlipRow xr = P.xrow[r];
             f_pos[t] = (uint32_t) pos;                      /* as read at a frontier >= Fl: the swap log brings it to column k */
             if (pos < Fl) { isU = 1; ulimbs += (uint32_t) slip_limbs(xr.len); nUc++; if ((uint32_t) xr.bits > maxubp) maxubp = (uint32_t) xr.bits; }
@@ -190,7 +190,7 @@ SLIP_DEV void slip_prepass(const SlipParams &P, const int k, const int tag, uint
                 cls = 3; isNP = 1;
                 int bh = 0, zh = 0;
                 SlipPiv H = slip_piv_none();
-                if (xr.h >= 0) { H = slip_ld_piv(&P.piv[xr.h]); bh = H.bits; zh = H.ctz; }
+                if (xr.h >= 0) { H = slip_ld_piv(P.piv.at(xr.h)); bh = H.bits; zh = H.ctz; }
                 c = xr.bits - bh + (xr.h >= 0 ? 1 : 0);
                 sB += (uint32_t)(((c > 0 ? c : 0) + 63) >> 6) + 1u; nB++;
                 if ((uint32_t)(c + SLIP_PP_BIAS) > maxcB) maxcB = (uint32_t)(c + SLIP_PP_BIAS);
@@ -395,7 +395,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
 #endif
             int Fn;
             /* still dry: the exported package holds for every pivot below the frontier this worker knows */
-            if (GATED && pp_fresh && tid == 0 && sv[SV_PKGX]) slip_st_u32(P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_STAMP, (uint32_t) Fl);
+            if (GATED && pp_fresh && tid == 0 && sv[SV_PKGX]) slip_st_u32(P.pkg.at() + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_STAMP, (uint32_t) Fl);
             Fn = -2;
             if (pp_want && sv[SV_NROWS] <= SLIP_TAB_CAP) {
                 if (!pp_fresh) {
@@ -467,7 +467,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
                     for (int c0 = Fl; c0 < Fn; c0 += 2 * SLIP_WORK_CAP) {
                         const int nc = Fn - c0 < 2 * SLIP_WORK_CAP ? Fn - c0 : 2 * SLIP_WORK_CAP;
                         slip_block_sync();
-                        for (int e = tid; e < nc; e += T) pv[e] = (uint32_t) slip_ld_i32(&P.row_perm[c0 + e]);
+                        for (int e = tid; e < nc; e += T) pv[e] = (uint32_t) slip_ld_i32(P.row_perm.at(c0 + e));
                         slip_block_sync();
                         for (int t = tid; t < nr; t += T) {
                             const uint32_t r = lrow[t];
@@ -477,7 +477,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
                 }
             } else
                 for (int c = Fl + tid; c < Fn; c += T) {
-                    const int r = slip_ld_i32(&P.row_perm[c]);
+                    const int r = slip_ld_i32(P.row_perm.at(c));
                     if (P.xrow[r].tag == tag) slip_atomic_or_u32(&bm[c >> 5], 1u << (c & 31));
                 }
             if (tid == 0) sv[SV_F] = Fn;
@@ -493,7 +493,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
              * rather than wait for it, hand the column to the chain engine with everything from position jn on still to be
              * applied -- the engine has the recent L columns in its LDS */
             slip_block_sync();
-            if (tid == 0) sv[SV_TMP2] = slip_agent_add_i32(&P.Lready[jn], 0) != 0;
+            if (tid == 0) sv[SV_TMP2] = slip_agent_add_i32(P.Lready.at(jn), 0) != 0;
             slip_block_sync();
             if (!sv[SV_TMP2]) {
                 {
@@ -527,12 +527,12 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
             if (tid == 0) sv[SV_F2] = f2;
             slip_block_sync();
         }
-        const int j = slip_ld_i32(&P.row_perm[jn]);
+        const int j = slip_ld_i32(P.row_perm.at(jn));
         SlipRow xj = P.xrow[j];
         uint64_t xjv = xj.len != 0 ? slip_limb0(P.xd + (int64_t) j * P.xcap) : 0;
-        const SlipPiv R = slip_ld_piv(&P.piv[jn]);
+        const SlipPiv R = slip_ld_piv(P.piv.at(jn));
         SlipPiv D = slip_piv_none();
-        if (jn >= 1) D = slip_ld_piv(&P.piv[jn - 1]);
+        if (jn >= 1) D = slip_ld_piv(P.piv.at(jn - 1));
         /* bring x[j] to its final value: history update to level jn-1 (:139-149) */
         if (xj.len != 0 && xj.h < jn - 1) {
             slip_u128 y = 0; int ys = 1;
@@ -602,7 +602,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
                     const int lx = xi.len != 0, has_d = jn >= 1;
                     const int hist = lx && has_d && xi.h < jn - 1, hdiv = hist && xi.h > -1;
                     SlipPiv H = slip_piv_none();
-                    if (hdiv) H = slip_ld_piv(&P.piv[xi.h]);
+                    if (hdiv) H = slip_ld_piv(P.piv.at(xi.h));
                     const int bxp = !lx ? 0 : (!hist ? xi.bits : (hdiv ? xi.bits + D.bits - H.bits + 1 : xi.bits + D.bits));
                     const int b1b = lx ? bxp + R.bits : 0, b2b = le.bits + xj.bits;
                     const int bnum = (b1b > b2b ? b1b : b2b) + 1;
@@ -630,7 +630,7 @@ SLIP_DEV int slip_sweep(const SlipParams &P, SlipState *st, const int k, const i
                 /* new rows join the row list; a row that is pivotal below the frontier becomes a later source */
                 slip_rlist_push(P, sv, lds, fresh, fi);
                 if (fresh) {
-                    const int pos = slip_ld_i32(&P.pinv[fi]);
+                    const int pos = slip_ld_i32(P.pinv.at(fi));
                     if (pos < Fl) slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
                 }
                 /* queue slots per wave: one LDS atomic per wave instead of one per update on the same counter */
@@ -712,7 +712,7 @@ SLIP_DEV int slip_publish_digits(dig_t *dst, const dig_t *src, int src_shared, i
 SLIP_DEV int slip_wait_verdict(const SlipParams &P, SlipState *st, uint32_t *lds, const int k, dig_t *b0, dig_t *b1, dig_t *b2)
 {
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
-    const uint32_t *pk = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;      /* this worker's mailbox */
+    const uint32_t *pk = P.pkg.at() + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;      /* this worker's mailbox */
     for (;;) {
         slip_block_sync();
         if (slip_tid() == 0) {
@@ -749,7 +749,7 @@ SLIP_DEV void slip_takeover_full(const SlipParams &P, const int k, const int tag
     uint32_t *f_row = lds + SLIP_LDS_TAB, *f_pos = f_row + SLIP_TAB_CAP;
     const uint32_t *f_npi = lds + SLIP_LDS_ROWS;
     uint32_t *t_row = lds + SLIP_LDS_KEYS, *t_pos = t_row + SLIP_PAT_CAP;
-    const uint32_t *mb = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;
+    const uint32_t *mb = P.pkg.at() + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;
     const int nold = sv[SV_NROWS], nU = sv[SV_PP + 3];
     const int nfin = (int) slip_ld_u32(mb + SLIP_PKG_OUT + 5);
     slip_block_sync();
@@ -830,7 +830,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         int row = 0;
         if (have) {
             row = P.Ai[p];
-            const int pos = slip_ld_i32(&P.pinv[row]);
+            const int pos = slip_ld_i32(P.pinv.at(row));
             if (pos < F0) slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));     /* pivotal below the frontier: a source */
             const int32_t al = P.Alen[p];
             const int la = slip_abs(al);
@@ -874,7 +874,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             if (tid == 0) {
                 /* sent back: for good (a value the engine does not handle), or until this worker has applied the source
                  * the engine could not (its column was committed elsewhere): the next full package must be a later one */
-                const uint32_t *mb_ = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;
+                const uint32_t *mb_ = P.pkg.at() + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;
                 if (slip_ld_u32(mb_ + SLIP_PKG_OUT + 1) != 1u) sv[SV_NOK1] = 1;
                 sv[SV_K1STAMP] = sv[SV_PKGF];
             }
@@ -936,16 +936,16 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     if (fastc) {
         if (wave == 0 && lane < sv[SV_PP + 1]) {
             c_t = (int) ppcl[lane]; c_r = (int) f_row[c_t];
-            c_pos = slip_ld_i32(&P.pinv[c_r]);
+            c_pos = slip_ld_i32(P.pinv.at(c_r));
             c_x = P.xrow[c_r];
         }
     } else if (tid < nrows) {
         r0_ = small ? (int) f_row[tid] : P.rlist[tid];
-        pos0_ = slip_ld_i32(&P.pinv[r0_]);
+        pos0_ = slip_ld_i32(P.pinv.at(r0_));
         if (try_early) xr0_ = P.xrow[r0_];
     }
     SlipPiv M = slip_piv_none();
-    if (k >= 1) M = slip_ld_piv(&P.piv[k - 1]);
+    if (k >= 1) M = slip_ld_piv(P.piv.at(k - 1));
     if (adopted) slip_agent_acquire();                   /* what the committer wrote for this column is read below */
     if (!fastc || wave == 0) {
         const int q_ = fastc ? lane - (SLIP_WAVE - 8) : tid - (T - 8);
@@ -953,8 +953,8 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         else if (q_ == 1) sv64[SV_LNL / 2] = slip_ld_i64(&P.Lo[k]);
         else if (q_ == 2) sv64[SV_UNZ / 2] = slip_ld_i64(&P.Up[k]);
         else if (q_ == 3) sv64[SV_UNL / 2] = slip_ld_i64(&P.Uo[k]);
-        else if (q_ == 4) sv[SV_TMP3] = slip_ld_i32(&P.pinv[col]);        /* position of the "diagonal" row: fixed until this column's swap */
-        else if (q_ == 5) sv[SV_TMP] = slip_ld_i32(&P.row_perm[k]);       /* the row the pivot will change places with                    */
+        else if (q_ == 4) sv[SV_TMP3] = slip_ld_i32(P.pinv.at(col));        /* position of the "diagonal" row: fixed until this column's swap */
+        else if (q_ == 5) sv[SV_TMP] = slip_ld_i32(P.row_perm.at(k));       /* the row the pivot will change places with                    */
         else if (q_ == 6) { sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_LISTN] = 0; }
     }
     const int lm = slip_abs(M.len), brho = M.bits;
@@ -1098,11 +1098,11 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                     SlipPiv pr; pr.off = poff; pr.len = pxr.len; pr.bits = pxr.bits; pr.ctz = z; pr.invlen = 0;
                     pr.lo = lo64; pr.inv64 = 0; pr.pad = 0;
                     if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
-                    slip_st_piv(&P.piv[k], pr);
+                    slip_st_piv(P.piv.at(k), pr);
                     const int intermed = e_pivpos, intermed2 = sv[SV_TMP];
-                    slip_st_i32(&P.row_perm[k], e_pivrow); slip_st_i32(&P.row_perm[intermed], intermed2);
-                    slip_st_i32(&P.pinv[e_pivrow], k); slip_st_i32(&P.pinv[intermed2], intermed);
-                    slip_st_i32(&P.sw_row[k], intermed2); slip_st_i32(&P.sw_pos[k], intermed);
+                    slip_st_i32(P.row_perm.at(k), e_pivrow); slip_st_i32(P.row_perm.at(intermed), intermed2);
+                    slip_st_i32(P.pinv.at(e_pivrow), k); slip_st_i32(P.pinv.at(intermed2), intermed);
+                    slip_st_i32(P.sw_row.at(k), intermed2); slip_st_i32(P.sw_pos.at(k), intermed);
                     slip_st_i64(&P.Up[k + 1], A.Unz_ + (int) A.nUc_all + 1); slip_st_i64(&P.Lp[k + 1], A.Lnz_ + A.nLc);
                     slip_st_i64(&P.Uo[k + 1], A.Unl_ + (int64_t)(A.U_l + plimbs)); slip_st_i64(&P.Lo[k + 1], A.Lnl_ + (int64_t) A.Lb_total);
                 }
@@ -1138,7 +1138,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     int ec = -1;                                 /* 0: committed early; > 0: a status; -1: the full pass below decides */
     if (adopted) {
         /* the committer has published this column's pivot: take over the outcome from this worker's mailbox */
-        const uint32_t *pk = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;
+        const uint32_t *pk = P.pkg.at() + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS;
         if (BMs) { const dig_t *Mg = slip_piv_digits(P, M); for (int c = tid; c < lm; c += T) Ms[c] = slip_ld_u32(Mg + c); }
         /* the position snapshot (pinv as the reference has it at column k): the value the pre-pass read at frontier stamp0, or
          * where the LAST swap in [stamp0, k) that displaced the row put it (positions of non-pivotal rows only ever grow, and a
@@ -1151,7 +1151,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             for (int e0 = stamp0; e0 < k; e0 += SLIP_PAT_CAP) {
                 const int ne = k - e0 < SLIP_PAT_CAP ? k - e0 : SLIP_PAT_CAP;
                 slip_block_sync();
-                for (int e = tid; e < ne; e += T) { lg_row[e] = (uint32_t) slip_ld_i32(&P.sw_row[e0 + e]); lg_pos[e] = (uint32_t) slip_ld_i32(&P.sw_pos[e0 + e]); }
+                for (int e = tid; e < ne; e += T) { lg_row[e] = (uint32_t) slip_ld_i32(P.sw_row.at(e0 + e)); lg_pos[e] = (uint32_t) slip_ld_i32(P.sw_pos.at(e0 + e)); }
                 slip_block_sync();
                 for (int q = 0; q < 4; q++)
                     if (myr[q] >= 0) for (int e = 0; e < ne; e++) if ((int) lg_row[e] == myr[q]) myp[q] = (int) lg_pos[e];
@@ -1287,7 +1287,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             /* the position snapshot (pinv as the reference has it at column k) by the other waves, before the swap */
             for (int t = tid - SLIP_WAVE; t < nrows; t += T - SLIP_WAVE) {
                 const int r = (int) f_row[t];
-                const int pos = slip_ld_i32(&P.pinv[r]);
+                const int pos = slip_ld_i32(P.pinv.at(r));
                 slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
                 f_pos[t] = (uint32_t) pos;
             }
@@ -1331,7 +1331,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             if (t0 == 0 && !fastc) { r = r0_; pos = pos0_; }  /* loaded above, with everything else */
             else {
                 r = small ? (int) f_row[t] : P.rlist[t];      /* short patterns: listed in LDS since their discovery */
-                pos = slip_ld_i32(&P.pinv[r]);
+                pos = slip_ld_i32(P.pinv.at(r));
             }
             slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
             if (small) f_pos[t] = (uint32_t) pos; else P.rpos[t] = pos;
@@ -1362,7 +1362,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
                 } else {
                     cls = 3;
                     int bh = 0, zh = 0;
-                    if (xr.h >= 0) { const SlipPiv H = slip_ld_piv(&P.piv[xr.h]); bh = H.bits; zh = H.ctz; }
+                    if (xr.h >= 0) { const SlipPiv H = slip_ld_piv(P.piv.at(xr.h)); bh = H.bits; zh = H.ctz; }
                     ub = xr.bits + brho - bh + (xr.h >= 0 ? 1 : 0);
                     if (ub < 1) ub = 1;
                     /* the item's working width (slip_history_wave) must fit the scratch, the x stride and the inverse cache */
@@ -1909,11 +1909,11 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
             SlipPiv pr; pr.off = poff; pr.len = plen; pr.bits = pbits; pr.ctz = z; pr.invlen = 0;
             pr.lo = lo64; pr.inv64 = 0; pr.pad = 0;
             if (lp_ <= 2) pr.inv64 = slip_inv64(pr.lo >> z);
-            slip_st_piv(&P.piv[k], pr);
-            const int intermed = pivpos, intermed2 = slip_ld_i32(&P.row_perm[k]);
-            slip_st_i32(&P.row_perm[k], pivrow); slip_st_i32(&P.row_perm[intermed], intermed2);
-            slip_st_i32(&P.pinv[pivrow], k); slip_st_i32(&P.pinv[intermed2], intermed);
-            slip_st_i32(&P.sw_row[k], intermed2); slip_st_i32(&P.sw_pos[k], intermed);
+            slip_st_piv(P.piv.at(k), pr);
+            const int intermed = pivpos, intermed2 = slip_ld_i32(P.row_perm.at(k));
+            slip_st_i32(P.row_perm.at(k), pivrow); slip_st_i32(P.row_perm.at(intermed), intermed2);
+            slip_st_i32(P.pinv.at(pivrow), k); slip_st_i32(P.pinv.at(intermed2), intermed);
+            slip_st_i32(P.sw_row.at(k), intermed2); slip_st_i32(P.sw_pos.at(k), intermed);
             slip_st_i64(&P.Up[k + 1], Unz + nUe); slip_st_i64(&P.Lp[k + 1], Lnz + nL);
             slip_st_i64(&P.Uo[k + 1], Unl + (int64_t) totU); slip_st_i64(&P.Lo[k + 1], Lnl + (int64_t) totL);
             slip_vm_drain();
@@ -1989,7 +1989,7 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
     slip_block_sync();
     if (tid == 0) {
         slip_agent_release();                            /* the column's plain stores (L entries, limbs) leave this XCD's L2 */
-        slip_agent_add_i32(&P.Lready[k], 1);             /* returning atomic: performed before the advance below reads the flags */
+        slip_agent_add_i32(P.Lready.at(k), 1);             /* returning atomic: performed before the advance below reads the flags */
         slip_advance_ready(P, st);
         slip_agent_add_u64(&st->c_write, 4ull * (unsigned long long) nE + 8ull * (totU + totLexact) + 8ull * slip_limbs(plen));
         slip_agent_add_u64((unsigned long long *) &st->Lnl_exact, totLexact);
@@ -2075,7 +2075,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
         const int32_t bl = A.blen[(int64_t) c * n + i];
         SlipRow r; r.len = bl; r.h = -1; r.tag = tag; r.bits = 0;
         if (bl != 0) {
-            const int pos = P.pinv[i], lb = slip_abs(bl);
+            const int pos = P.pinv.fixed(i), lb = slip_abs(bl);
             slip_atomic_or_u32(&bm[pos >> 5], 1u << (pos & 31));
             const dig_t *src = (const dig_t *)(A.blimbs + A.boff[(int64_t) c * n + i]);
             dig_t *X = P.xd + (int64_t) i * P.xcap;
@@ -2107,14 +2107,14 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
         volatile int32_t *wcnt = &sv[SV_CNT0];
         if (tid == 0) *wcnt = 0;
         slip_block_sync();
-        const SlipPiv Mdet = slip_ld_piv(&P.piv[n - 1]);
+        const SlipPiv Mdet = slip_ld_piv(P.piv.at(n - 1));
         for (int t0 = 0; t0 < npat; t0 += SLIP_WORK_CAP) {
             const int te = t0 + SLIP_WORK_CAP < npat ? t0 + SLIP_WORK_CAP : npat;
             for (int tb = t0; tb < te; tb += T) {
                 const int t = tb + tid;
                 int queue = 0, r = 0;
                 if (t < te) do {
-                    r = P.row_perm[pat_at(t)];
+                    r = P.row_perm.fixed(pat_at(t));
                     const SlipRow xr = P.xrow[r];
                     if (xr.len == 0) break;
                     slip_u128 y = 0; int ys = 1; int done = 0;
@@ -2149,10 +2149,10 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
             const int jp = slip_bitmap_prev(bm, cur);
             if (jp < 0) break;
             cur = jp;
-            const int j = P.row_perm[jp];
+            const int j = P.row_perm.fixed(jp);
             SlipRow xj = P.xrow[j];
             if (xj.tag != tag || xj.len == 0) continue;
-            const SlipPiv Dj = slip_ld_piv(&P.piv[jp]);
+            const SlipPiv Dj = slip_ld_piv(P.piv.at(jp));
             if (slip_abs(xj.len) <= 2 && slip_abs(Dj.len) <= 2) {
                 const slip_u128 y = slip_divexact128((slip_u128) slip_limb0(P.xd + (int64_t) j * P.xcap), Dj.lo, Dj.ctz, Dj.inv64);
                 slip_block_sync();                                 /* every thread has read the old value */
@@ -2174,7 +2174,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
                     if (m < me) do {
                     const int i = P.Ui[m];
                     const SlipEnt ue = P.Ue[m];
-                    const int pos = P.pinv[i];
+                    const int pos = P.pinv.fixed(i);
                     SlipRow xi = P.xrow[i];
                     if (xi.tag != tag) {
                         xi.len = 0; xi.h = -1; xi.bits = 0; xi.tag = tag; P.xrow[i] = xi;
@@ -2229,7 +2229,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
         for (int p0 = 0; p0 < n; p0 += T) {
             const int pos = p0 + tid;
             int32_t xl = 0; int r = -1;
-            if (pos < n && ((bm[pos >> 5] >> (pos & 31)) & 1u)) { r = P.row_perm[pos]; xl = P.xrow[r].len; }
+            if (pos < n && ((bm[pos >> 5] >> (pos & 31)) & 1u)) { r = P.row_perm.fixed(pos); xl = P.xrow[r].len; }
             uint64_t e0, e1, t0_, t1_;
             slip_block_scan2((uint64_t) slip_limbs(xl), 0, scan_tmp, &e0, &e1, &t0_, &t1_);
             if (pos < n) {

@@ -90,7 +90,7 @@ SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *ld
     const uint32_t *f_row = lds + SLIP_LDS_TAB, *f_pos = f_row + SLIP_TAB_CAP, *f_aux = f_row + 3 * SLIP_TAB_CAP;
     const uint32_t *f_k0 = lds + SLIP_LDS_KEYS, *f_k1 = f_k0 + SLIP_PAT_CAP;
     const uint32_t *cl = lds + SLIP_LDS_WORK + SLIP_CAND_CAP;
-    uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
+    uint32_t *pk = P.pkg.at() + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
     const int nrows = sv[SV_NROWS], ncand = sv[SV_PP + 1];
     const uint32_t ver = ((uint32_t) sv[SV_PKGVER] | 1u) + 1u;          /* 2, 4, 6, ... */
     if (tid == 0) { slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t)(ver - 1u) << 32) | (uint32_t)(k + 1)); slip_vm_drain(); }
@@ -107,7 +107,7 @@ SLIP_DEV void slip_export_package(const SlipParams &P, const int k, uint32_t *ld
         slip_st_u32(pk + SLIP_PKG_STAMP, (uint32_t) Fl); slip_st_u32(pk + SLIP_PKG_STAMP0, (uint32_t) F0);
         slip_st_u32(pk + SLIP_PKG_NROWS, (uint32_t) nrows); slip_st_u32(pk + SLIP_PKG_VER, ver); slip_st_u32(pk + SLIP_PKG_WORKER, (uint32_t) P.worker);
         slip_st_u32(pk + SLIP_PKG_KIND, 0u); slip_st_u32(pk + SLIP_PKG_NFULL, 0u);
-        slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS + SLIP_PKG_OUT, 0u);
+        slip_st_u32(P.pkg.at() + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS + SLIP_PKG_OUT, 0u);
     }
     slip_vm_drain();
     slip_block_sync();
@@ -128,7 +128,7 @@ SLIP_DEV void slip_export_full(const SlipParams &P, const int k, uint32_t *lds, 
     const uint32_t *f_row = lds + SLIP_LDS_TAB;
     const uint32_t *f_k0 = lds + SLIP_LDS_KEYS, *f_k1 = f_k0 + SLIP_PAT_CAP;
     const uint32_t *f_meta = lds + SLIP_LDS_DIROFF, *f_npi = lds + SLIP_LDS_ROWS;
-    uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
+    uint32_t *pk = P.pkg.at() + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
     const int nrows = sv[SV_NROWS], nnp = sv[SV_PPF];
     const uint32_t ver = ((uint32_t) sv[SV_PKGVER] | 1u) + 1u;
     if (tid == 0) { slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t)(ver - 1u) << 32) | (uint32_t)(k + 1)); slip_vm_drain(); }
@@ -145,7 +145,7 @@ SLIP_DEV void slip_export_full(const SlipParams &P, const int k, uint32_t *lds, 
         slip_st_u32(pk + SLIP_PKG_STAMP, (uint32_t) Fl); slip_st_u32(pk + SLIP_PKG_STAMP0, (uint32_t) F0);
         slip_st_u32(pk + SLIP_PKG_NROWS, (uint32_t) nrows); slip_st_u32(pk + SLIP_PKG_VER, ver); slip_st_u32(pk + SLIP_PKG_WORKER, (uint32_t) P.worker);
         slip_st_u32(pk + SLIP_PKG_KIND, 1u); slip_st_u32(pk + SLIP_PKG_NFULL, (uint32_t) nnp);
-        slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS + SLIP_PKG_OUT, 0u);
+        slip_st_u32(P.pkg.at() + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) P.worker * SLIP_MBOX_WORDS + SLIP_PKG_OUT, 0u);
     }
     slip_vm_drain();
     slip_block_sync();
@@ -159,7 +159,7 @@ SLIP_DEV void slip_export_full(const SlipParams &P, const int k, uint32_t *lds, 
 /* the worker's side: the package no longer describes the rows (thread 0) */
 SLIP_DEV void slip_retract_package(const SlipParams &P, const int k, volatile int32_t *sv)
 {
-    uint32_t *pk = P.pkg + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
+    uint32_t *pk = P.pkg.at() + (int64_t)(k % P.nworkers) * SLIP_PKG_WORDS;
     const uint32_t ver = (uint32_t) sv[SV_PKGVER] | 1u;
     slip_st_u64((uint64_t *)(pk + SLIP_PKG_HDR), ((uint64_t) ver << 32) | (uint32_t)(k + 1));
     sv[SV_PKGVER] = (int32_t) ver; sv[SV_PKGX] = 0;
@@ -261,10 +261,10 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         int pr_; const int F0 = slip_ld_frontier(st, &pr_);
         sv[C_K] = F0; sv[C_HAVE] = 0; sv[C_RING0] = F0; sv[C_REJ] = -1; sv[C_REJV] = 0; sv[C_LW] = 0; sv[C_PR0] = F0;
         for (int q = 0; q < 8; q++) eacc[q] = 0ull;
-        if (F0 >= 1) { const SlipPiv pv = slip_ld_piv(&P.piv[F0 - 1]); pring_put(F0 - 1, pv); sv[C_PR0] = F0 - 1; }
+        if (F0 >= 1) { const SlipPiv pv = slip_ld_piv(P.piv.at(F0 - 1)); pring_put(F0 - 1, pv); sv[C_PR0] = F0 - 1; }
     }
     for (int w = tid; w < SLIP_CB_RING; w += T) { ld_col[w] = 0xFFFFFFFFu; ld_cnt[w] = 0xFFFFFFFFu; }
-    if (mirror) for (int i = tid; i < P.n; i += T) { pinvm[i] = (uint16_t) slip_ld_i32(&P.pinv[i]); slotm[i] = 0; }
+    if (mirror) for (int i = tid; i < P.n; i += T) { pinvm[i] = (uint16_t) slip_ld_i32(P.pinv.at(i)); slotm[i] = 0; }
     slip_block_sync();
     if (tid == 0) slip_agent_store_i32(&st->committer_up, 1);       /* from now on packages are answered */
 #ifdef SLIP_PROFILE_COMMIT
@@ -312,16 +312,16 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     /* columns committed by their workers: their swaps from the log every publisher keeps, their pivots */
                     const int lo_c = kc - kprev > SLIP_CB_RING ? kc - SLIP_CB_RING : kprev;
                     for (int c = lo_c + lane; c < kc; c += SLIP_WAVE) {
-                        ring_row[c & (SLIP_CB_RING - 1)] = (uint32_t) slip_ld_i32(&P.row_perm[c]);
-                        ring_disp[c & (SLIP_CB_RING - 1)] = (uint32_t) slip_ld_i32(&P.sw_row[c]);
-                        ring_opos[c & (SLIP_CB_RING - 1)] = (uint32_t) slip_ld_i32(&P.sw_pos[c]);
-                        const SlipPiv pv = slip_ld_piv(&P.piv[c]);
+                        ring_row[c & (SLIP_CB_RING - 1)] = (uint32_t) slip_ld_i32(P.row_perm.at(c));
+                        ring_disp[c & (SLIP_CB_RING - 1)] = (uint32_t) slip_ld_i32(P.sw_row.at(c));
+                        ring_opos[c & (SLIP_CB_RING - 1)] = (uint32_t) slip_ld_i32(P.sw_pos.at(c));
+                        const SlipPiv pv = slip_ld_piv(P.piv.at(c));
                         pring_put(c, pv);
                         ld_col[c & (SLIP_CB_RING - 1)] = 0xFFFFFFFFu;       /* its L column is not in the engine's ring */
                     }
                     slip_wave_sync_lds();
                     if (mirror) {
-                        if (lo_c > kprev) { for (int i = lane; i < P.n; i += SLIP_WAVE) pinvm[i] = (uint16_t) slip_ld_i32(&P.pinv[i]); }     /* fell behind the ring: start over from memory (every swap below kc has landed) */
+                        if (lo_c > kprev) { for (int i = lane; i < P.n; i += SLIP_WAVE) pinvm[i] = (uint16_t) slip_ld_i32(P.pinv.at(i)); }     /* fell behind the ring: start over from memory (every swap below kc has landed) */
                         else if (lane == 0) for (int c = kprev; c < kc; c++) {
                             const int s_ = c & (SLIP_CB_RING - 1);
 #if defined(SLIP_EMULATE) && defined(SLIP_EMU_TRACE)
@@ -340,7 +340,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 if (kc >= P.k_stop || (stop >> 8) <= (int64_t) kc) { go = 0; break; }
                 const int j = kc + lane;
                 uint64_t h = 0;
-                if (lane < SLIP_CB && j < P.k_stop && (stop >> 8) > (int64_t) j) h = slip_ld_u64((const uint64_t *)(P.pkg + (int64_t)(j % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_HDR));
+                if (lane < SLIP_CB && j < P.k_stop && (stop >> 8) > (int64_t) j) h = slip_ld_u64((const uint64_t *)(P.pkg.at() + (int64_t)(j % P.nworkers) * SLIP_PKG_WORDS + SLIP_PKG_HDR));
                 const uint32_t hw_ = (uint32_t)(h >> 32), hv = hw_ & 0xFFu;        /* version; above it the sizes of the package */
                 const int rdy = (uint32_t) h == (uint32_t)(j + 1) && hv >= 2u && !(hv & 1u) && !(j == sv[C_REJ] && hv == (uint32_t) sv[C_REJV]);
                 if (lane < SLIP_CB) { hver[lane] = hv; hver[SLIP_CB + lane] = hw_; }
@@ -360,13 +360,13 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         /* (b) the packages into LDS (one wave per column) and what can be said about each by itself */
         for (int i = wave; i < nb; i += nw) {
             const int j = kc + i;
-            const uint32_t *pk = P.pkg + (int64_t)(j % P.nworkers) * SLIP_PKG_WORDS;
+            const uint32_t *pk = P.pkg.at() + (int64_t)(j % P.nworkers) * SLIP_PKG_WORDS;
             uint32_t *cb = cbuf + i * SLIP_CBW;
             if (lane < SLIP_PP_WORDS) cb[lane] = slip_ld_u32(pk + SLIP_PKG_SUMS + lane);
             else if (lane == 14) cb[14] = slip_ld_u32(pk + SLIP_PKG_STAMP);
             else if (lane == 15) cb[15] = slip_ld_u32(pk + SLIP_PKG_STAMP0);
             else if (lane == 16) cb[16] = slip_ld_u32(pk + SLIP_PKG_NROWS);
-            else if (lane == 17) cb[17] = (uint32_t) slip_ld_i32(&P.row_perm[j]);
+            else if (lane == 17) cb[17] = (uint32_t) slip_ld_i32(P.row_perm.at(j));
             else if (lane == 18) cb[18] = 0u;
             else if (lane == 19) cb[19] = slip_ld_u32(pk + SLIP_PKG_VER);
             else if (lane == 20) cb[20] = slip_ld_u32(pk + SLIP_PKG_WORKER);
@@ -480,7 +480,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             if (tid == T - 2) sv64[SV_LNL / 2] = slip_ld_i64(&P.Lo[kc]);
             if (tid == T - 3) sv64[SV_UNZ / 2] = slip_ld_i64(&P.Up[kc]);
             if (tid == T - 4) sv64[SV_UNL / 2] = slip_ld_i64(&P.Uo[kc]);
-            if (tid == T - 5) *Mrec = slip_ld_piv(&P.piv[kc - 1]);       /* kc >= 1: column 0 is never packaged */
+            if (tid == T - 5) *Mrec = slip_ld_piv(P.piv.at(kc - 1));       /* kc >= 1: column 0 is never packaged */
         }
         slip_block_sync();
         /* (b2) a row of the pattern that becomes pivotal earlier in this batch sends the package back (the pivots before the batch
@@ -535,7 +535,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             uint32_t bs_row = 0xFFFFFFFFu, bs_disp = 0xFFFFFFFFu, bs_opos = 0xFFFFFFFFu;
             const int xcap_ = P.xcap, wcapP = P.wcap, invcap_ = P.invcap, limb_cap_ = P.limb_cap, nworkers_ = P.nworkers;
             const int64_t Lcap_nz_ = P.Lcap_nz, Lcap_nl_ = P.Lcap_nl, Ucap_nz_ = P.Ucap_nz, Ucap_nl_ = P.Ucap_nl;
-            uint32_t *const mbox0 = P.pkg + (int64_t) nworkers_ * SLIP_PKG_WORDS;
+            uint32_t *const mbox0 = P.pkg.at() + (int64_t) nworkers_ * SLIP_PKG_WORDS;
             for (int i = 0; i < nb; i++) {
                 const int j = kc + i;
                 uint32_t *cb = cbuf + i * SLIP_CBW;
@@ -723,7 +723,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                             /* L(:,c) is not in the ring (its worker committed it, or it was pushed out): from memory if its worker has
                              * published it (stage 2, Lready[c]) -- otherwise the package goes back and its worker waits for that */
                             int rdy = 0;
-                            if (lane == 0) rdy = slip_agent_load_i32(&P.Lready[c]);
+                            if (lane == 0) rdy = slip_agent_load_i32(P.Lready.at(c));
                             rdy = (int) slip_bcast0_u32((uint32_t) rdy);
                             if (!rdy) { reject = 1; break; }
                             const int64_t m0 = slip_ld_i64(&P.Lp[c]), m1 = slip_ld_i64(&P.Lp[c + 1]);
@@ -1024,10 +1024,10 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                     {
                         uint32_t *a4 = (uint32_t *) 0; uint32_t v4 = 0;
                         switch (lane) {
-                            case 0: a4 = (uint32_t *) &P.row_perm[j]; v4 = (uint32_t) e_pivrow; break;
-                            case 1: a4 = (uint32_t *) &P.row_perm[e_pivpos]; v4 = (uint32_t) intermed2; break;
-                            case 2: a4 = (uint32_t *) &P.pinv[e_pivrow]; v4 = (uint32_t) j; break;
-                            case 3: a4 = (uint32_t *) &P.pinv[intermed2]; v4 = (uint32_t) e_pivpos; break;
+                            case 0: a4 = (uint32_t *) P.row_perm.at(j); v4 = (uint32_t) e_pivrow; break;
+                            case 1: a4 = (uint32_t *) P.row_perm.at(e_pivpos); v4 = (uint32_t) intermed2; break;
+                            case 2: a4 = (uint32_t *) P.pinv.at(e_pivrow); v4 = (uint32_t) j; break;
+                            case 3: a4 = (uint32_t *) P.pinv.at(intermed2); v4 = (uint32_t) e_pivpos; break;
                             default: break;
                         }
                         /* (lanes of ONE store instruction to one address have no order: when the pivot already sits at position j,
@@ -1064,7 +1064,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             const int j = kc + i;
             const uint32_t *pb = pub + i * SLIP_PUBW;
             const dig_t *src = stage + i * SLIP_CB_SLOTW;
-            uint32_t *mbx = P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) pb[20] * SLIP_MBOX_WORDS;
+            uint32_t *mbx = P.pkg.at() + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) pb[20] * SLIP_MBOX_WORDS;
             const int e_pivrow = (int) pb[0], e_pivpos = (int) pb[1], intermed2 = (int) pb[2], lp_ = (int) pb[5];
             const int64_t poff = (int64_t)((uint64_t) pb[8] | ((uint64_t) pb[9] << 32));
             const int z = slip_publish_digits((dig_t *)(P.Llimbs + poff), src, 0, lp_);
@@ -1074,7 +1074,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
             /* every lane computes the same values; lane q issues store q: two store instructions instead of twenty-odd */
             {
                 uint64_t *a8 = (uint64_t *) 0; uint64_t v8 = 0;
-                uint64_t *pw = (uint64_t *) &P.piv[j];
+                uint64_t *pw = (uint64_t *) P.piv.at(j);
                 switch (lane) {
                     case 0: a8 = pw; v8 = (uint64_t) pr.off; break;
                     case 1: a8 = pw + 1; v8 = (uint64_t)(uint32_t) pr.len | ((uint64_t)(uint32_t) pr.bits << 32); break;
@@ -1094,13 +1094,13 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 uint32_t *a4 = (uint32_t *) 0; uint32_t v4 = 0;
                 switch (lane) {
 #ifdef SLIP_EMU_BUG_PERM
-                    case 0: a4 = (uint32_t *) &P.row_perm[j]; v4 = (uint32_t) e_pivrow; break;
-                    case 1: a4 = (uint32_t *) &P.row_perm[e_pivpos]; v4 = (uint32_t) intermed2; break;
-                    case 2: a4 = (uint32_t *) &P.pinv[e_pivrow]; v4 = (uint32_t) j; break;
-                    case 3: a4 = (uint32_t *) &P.pinv[intermed2]; v4 = (uint32_t) e_pivpos; break;
+                    case 0: a4 = (uint32_t *) P.row_perm.at(j); v4 = (uint32_t) e_pivrow; break;
+                    case 1: a4 = (uint32_t *) P.row_perm.at(e_pivpos); v4 = (uint32_t) intermed2; break;
+                    case 2: a4 = (uint32_t *) P.pinv.at(e_pivrow); v4 = (uint32_t) j; break;
+                    case 3: a4 = (uint32_t *) P.pinv.at(intermed2); v4 = (uint32_t) e_pivpos; break;
 #endif
-                    case 4: a4 = (uint32_t *) &P.sw_row[j]; v4 = (uint32_t) intermed2; break;
-                    case 5: a4 = (uint32_t *) &P.sw_pos[j]; v4 = (uint32_t) e_pivpos; break;
+                    case 4: a4 = (uint32_t *) P.sw_row.at(j); v4 = (uint32_t) intermed2; break;
+                    case 5: a4 = (uint32_t *) P.sw_pos.at(j); v4 = (uint32_t) e_pivpos; break;
                     case 6: a4 = mbx + SLIP_PKG_OUT + 1; v4 = (uint32_t) e_pivrow; break;
                     case 7: a4 = mbx + SLIP_PKG_OUT + 2; v4 = (uint32_t) e_pivpos; break;
                     case 8: a4 = mbx + SLIP_PKG_OUT + 3; v4 = pb[3]; break;
@@ -1118,7 +1118,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
         /* (e) the verdicts and the frontier */
         if (wave == 0) {
             slip_vm_drain();
-            if (lane < nbc) slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t)(pub + lane * SLIP_PUBW)[20] * SLIP_MBOX_WORDS + SLIP_PKG_OUT, (hver[lane] << 24) | (uint32_t)(kc + lane + 1));
+            if (lane < nbc) slip_st_u32(P.pkg.at() + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t)(pub + lane * SLIP_PUBW)[20] * SLIP_MBOX_WORDS + SLIP_PKG_OUT, (hver[lane] << 24) | (uint32_t)(kc + lane + 1));
 #ifdef SLIP_PROFILE_PHASES
             if (lane < nbc) P.dbg[18 * (int64_t) P.n + 6 * (int64_t)(kc + lane) + 2] = (int32_t) slip_realtime();  /* time line 2: committed by the committer */
 #endif
@@ -1126,7 +1126,7 @@ SLIP_DEV void slip_committer(const SlipParams &P, SlipState *st, uint32_t *lds)
                 if (rej >= 0) {
                     const uint32_t rv = hver[rej - kc];
                     const uint32_t rw = (cbuf + (rej - kc) * SLIP_CBW)[20];
-                    if (rw < (uint32_t) P.nworkers) slip_st_u32(P.pkg + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) rw * SLIP_MBOX_WORDS + SLIP_PKG_OUT, (uint32_t)(-(int32_t)((rv << 24) | (uint32_t)(rej + 1))));
+                    if (rw < (uint32_t) P.nworkers) slip_st_u32(P.pkg.at() + (int64_t) P.nworkers * SLIP_PKG_WORDS + (int64_t) rw * SLIP_MBOX_WORDS + SLIP_PKG_OUT, (uint32_t)(-(int32_t)((rv << 24) | (uint32_t)(rej + 1))));
                     sv[C_REJ] = rej; sv[C_REJV] = (int32_t) rv;
                 }
                 if (nbc > 0) {

@@ -577,7 +577,7 @@ static int alloc_x(slip_hip_factor *f, int32_t xcap, int keep_rows)
         /* tags start at 0 = "belongs to no column"; tickets count from 1 */
         else if (hipMemset(nxrow, 0, (size_t)(W * n) * sizeof(SlipRow)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     }
-    if (!rc && (!keep_rows || !P->pkg)) {
+    if (!rc && (!keep_rows || !P->pkg.p_)) {
         if (dev_alloc(&npkg, W * (int64_t)(SLIP_PKG_WORDS + SLIP_MBOX_WORDS)) || dev_alloc(&njobs, W * (int64_t) SLIP_JOB_WORDS)) rc = SLIP_HIP_OUT_OF_MEMORY;
         else if (hipMemset(njobs, 0, (size_t) W * SLIP_JOB_WORDS * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     }
@@ -587,13 +587,13 @@ static int alloc_x(slip_hip_factor *f, int32_t xcap, int keep_rows)
         if (old_xcap > 0) { P->xcap = old_xcap; P->invcap = old_invcap; f->waves = old_waves; plan_launch(f); }
         return rc;
     }
-    hipFree(P->xd); hipFree(P->invd); hipFree(P->gscratch); hipFree(P->gbitmap);
-    P->xd = nxd; P->invd = ninvd; P->gscratch = ngs; P->gbitmap = ngb;
+    hipFree(P->xd); hipFree(P->invd.p_); hipFree(P->gscratch); hipFree(P->gbitmap);
+    P->xd = nxd; P->invd.p_ = ninvd; P->gscratch = ngs; P->gbitmap = ngb;
     if (!keep_rows) {
         hipFree(P->xrow); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow);
         P->xrow = nxrow; P->pat = npat; P->rlist = nrlist; P->rpos = nrpos; P->srow = nsrow;
     }
-    if (npkg) { hipFree(P->pkg); hipFree(P->jobs); P->pkg = npkg; P->jobs = njobs; }
+    if (npkg) { hipFree(P->pkg.p_); hipFree(P->jobs.p_); P->pkg.p_ = npkg; P->jobs.p_ = njobs; }
     f->nworkers = W32; P->nworkers = W32; P->priv_rows = n;
     return 0;
 }
@@ -617,9 +617,9 @@ extern "C" int slip_hip_factor_reset(slip_hip_factor *f)
         CK(hipMemsetAsync(P->xrow, 0, (size_t)((int64_t) f->nworkers * n) * sizeof(SlipRow), 0));
         f->hs.ticket = 0;
     }
-    CK(hipMemcpyAsync(P->pinv, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
-    CK(hipMemcpyAsync(P->row_perm, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
-    CK(hipMemsetAsync(P->Lready, 0, (size_t) n * 4, 0));
+    CK(hipMemcpyAsync(P->pinv.p_, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
+    CK(hipMemcpyAsync(P->row_perm.p_, f->ident, (size_t) n * 4, hipMemcpyDeviceToDevice, 0));
+    CK(hipMemsetAsync(P->Lready.p_, 0, (size_t) n * 4, 0));
     CK(hipMemsetAsync(P->Lp, 0, 8, 0)); CK(hipMemsetAsync(P->Up, 0, 8, 0));
     CK(hipMemsetAsync(P->Lo, 0, 8, 0)); CK(hipMemsetAsync(P->Uo, 0, 8, 0));
     {
@@ -639,11 +639,11 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
     if (!f) return;
     SlipParams *P = &f->P;
     hipFree(f->dAp); hipFree(f->dAi); hipFree(f->dAlen); hipFree(f->dAoff); hipFree(f->dAlimbs); hipFree(f->dq);
-    hipFree(P->pinv); hipFree(P->row_perm); hipFree(P->xrow); hipFree(P->xd);
-    hipFree(P->piv); hipFree(P->invd);
+    hipFree(P->pinv.p_); hipFree(P->row_perm.p_); hipFree(P->xrow); hipFree(P->xd);
+    hipFree(P->piv.p_); hipFree(P->invd.p_);
     hipFree(P->Lp); hipFree(P->Lo); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
     hipFree(P->Up); hipFree(P->Uo); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
-    hipFree(P->Lready); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg); hipFree(P->pkg); hipFree(P->jobs); hipFree(P->sw_row); hipFree(P->sw_pos);
+    hipFree(P->Lready.p_); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg); hipFree(P->pkg.p_); hipFree(P->jobs.p_); hipFree(P->sw_row.p_); hipFree(P->sw_pos.p_);
     hipFree(f->ds); hipFree(f->ident);
     rescale_drop(f);
     if (f->ev0) hipEventDestroy(f->ev0);
@@ -760,11 +760,11 @@ extern "C" int slip_hip_factor_create(slip_hip_factor **out, int32_t n,
 #define A_(call) do { if (!rc) rc = (call); } while (0)
     A_(dev_alloc(&f->dAp, (int64_t) n + 1)); A_(dev_alloc(&f->dAi, onz)); A_(dev_alloc(&f->dAlen, onz));
     A_(dev_alloc(&f->dAoff, onz)); A_(dev_alloc(&f->dAlimbs, ol)); A_(dev_alloc(&f->dq, n));
-    A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n + 4096)); A_(dev_alloc(&P->sw_row, n)); A_(dev_alloc(&P->sw_pos, n));
+    A_(dev_alloc(&P->pinv.p_, n)); A_(dev_alloc(&P->row_perm.p_, n));
+    A_(dev_alloc(&P->piv.p_, n)); A_(dev_alloc(&P->Lready.p_, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n + 4096)); A_(dev_alloc(&P->sw_row.p_, n)); A_(dev_alloc(&P->sw_pos.p_, n));
     A_(make_ident(f));
     if (!rc && hipMemset(P->dbg, 0, ((size_t) n * 24 + 4096) * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
-    if (!rc && hipMemset(P->piv, 0, (size_t) n * sizeof(SlipPiv)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
+    if (!rc && hipMemset(P->piv.p_, 0, (size_t) n * sizeof(SlipPiv)) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     /* initial sizes: S->lnz/unz only size the first allocation in the reference too */
     P->Lcap_nz = opt.lnz_hint > 0 ? opt.lnz_hint : 4 * onz + n;
     P->Ucap_nz = opt.unz_hint > 0 ? opt.unz_hint : 4 * onz + n;
@@ -810,14 +810,14 @@ static int grow_x_keep(slip_hip_factor *f, int64_t xcap, int32_t K)
     if (K > 0) {
         keep = (SlipPiv *) malloc((size_t) K * sizeof(SlipPiv));
         if (!keep) return SLIP_HIP_OUT_OF_MEMORY;
-        if (hipMemcpy(keep, P->piv, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(keep); return SLIP_HIP_DEVICE_ERROR; }
+        if (hipMemcpy(keep, P->piv.p_, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(keep); return SLIP_HIP_DEVICE_ERROR; }
     }
     /* a wider stride may change how many workers fit: alloc_x re-applies the HBM budget at the new stride and never goes
      * beyond the count the private row arrays were sized for; on failure the handle keeps its old buffers */
     int e = alloc_x(f, (int32_t) xcap, 1);
     if (!e && K > 0) {
         for (int32_t k = 0; k < K; k++) keep[k].invlen = 0;
-        if (hipMemcpy(P->piv, keep, (size_t) K * sizeof(SlipPiv), hipMemcpyHostToDevice) != hipSuccess) e = SLIP_HIP_DEVICE_ERROR;
+        if (hipMemcpy(P->piv.p_, keep, (size_t) K * sizeof(SlipPiv), hipMemcpyHostToDevice) != hipSuccess) e = SLIP_HIP_DEVICE_ERROR;
     }
     free(keep);
     return e;
@@ -847,16 +847,16 @@ static int launch_columns(slip_hip_factor *f, hipStream_t stream)
     /* no more workers than columns left */
     int32_t W = f->nworkers;
     /* block 0 of a launch with at least two workgroups of at least two waves is the committer (ref_lu_pipe_commit.h) */
-    f->P.committer = W >= 2 && f->waves >= 2 && f->bitmap_in_lds && f->scratch_in_lds && !f->P.no_early && !f->no_committer && f->P.pivot_scheme != 2 && f->P.pkg != NULL;
+    f->P.committer = W >= 2 && f->waves >= 2 && f->bitmap_in_lds && f->scratch_in_lds && !f->P.no_early && !f->no_committer && f->P.pivot_scheme != 2 && f->P.pkg.p_ != NULL;
     if (W > f->P.k_stop - f->hs.F + f->P.committer) W = f->P.k_stop - f->hs.F + f->P.committer;
     if (W < 1) W = 1;
     if (W < 2) f->P.committer = 0;
     if (f->P.committer && slip_commit_lds_words(f->P.n, 0) > f->lds_words) f->P.committer = 0;      /* (cannot happen: plan_launch made room) */
     f->P.engine = f->P.committer && f->engine_ok && slip_commit_lds_words(f->P.n, 1) <= f->lds_words;
     f->P.nworkers = W;
-    if (f->P.committer) CK(hipMemsetAsync(f->P.pkg, 0, (size_t) W * (SLIP_PKG_WORDS + SLIP_MBOX_WORDS) * 4, stream));
-    f->P.farm = W >= 2 && !f->no_farm && f->P.jobs != NULL;
-    if (f->P.farm) CK(hipMemsetAsync(f->P.jobs, 0, (size_t) W * SLIP_JOB_WORDS * 4, stream));
+    if (f->P.committer) CK(hipMemsetAsync(f->P.pkg.p_, 0, (size_t) W * (SLIP_PKG_WORDS + SLIP_MBOX_WORDS) * 4, stream));
+    f->P.farm = W >= 2 && !f->no_farm && f->P.jobs.p_ != NULL;
+    if (f->P.farm) CK(hipMemsetAsync(f->P.jobs.p_, 0, (size_t) W * SLIP_JOB_WORDS * 4, stream));
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;
@@ -1020,8 +1020,8 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     P->Lcap_nz = lnz; P->Ucap_nz = unz; P->Lcap_nl = lnl > 0 ? lnl : 1; P->Ucap_nl = unl > 0 ? unl : 1;
     int rc = 0;
 #define A_(call) do { if (!rc) rc = (call); } while (0)
-    A_(dev_alloc(&P->pinv, n)); A_(dev_alloc(&P->row_perm, n));
-    A_(dev_alloc(&P->piv, n)); A_(dev_alloc(&P->Lready, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n + 4096)); A_(dev_alloc(&P->sw_row, n)); A_(dev_alloc(&P->sw_pos, n));
+    A_(dev_alloc(&P->pinv.p_, n)); A_(dev_alloc(&P->row_perm.p_, n));
+    A_(dev_alloc(&P->piv.p_, n)); A_(dev_alloc(&P->Lready.p_, n)); A_(dev_alloc(&P->dbg, 24 * (int64_t) n + 4096)); A_(dev_alloc(&P->sw_row.p_, n)); A_(dev_alloc(&P->sw_pos.p_, n));
     A_(dev_alloc(&P->Lp, (int64_t) n + 1)); A_(dev_alloc(&P->Lo, (int64_t) n + 1)); A_(dev_alloc(&P->Li, lnz)); A_(dev_alloc(&P->Le, lnz)); A_(dev_alloc(&P->Llimbs, P->Lcap_nl));
     A_(dev_alloc(&P->Up, (int64_t) n + 1)); A_(dev_alloc(&P->Uo, (int64_t) n + 1)); A_(dev_alloc(&P->Ui, unz)); A_(dev_alloc(&P->Ue, unz)); A_(dev_alloc(&P->Ulimbs, P->Ucap_nl));
     A_(dev_alloc(&f->ds, 1));
@@ -1029,7 +1029,7 @@ extern "C" int slip_hip_factor_from_factors(slip_hip_factor **out, int32_t n,
     if (!rc) rc = alloc_x(f, 2 * maxdig + 8, 0);
 #undef A_
 #define UP_(dst, src, bytes) do { if (!rc && (bytes) > 0 && hipMemcpy((void *)(dst), (src), (size_t)(bytes), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR; } while (0)
-    UP_(P->pinv, pinv, (size_t) n * 4); UP_(P->row_perm, rowperm, (size_t) n * 4); UP_(P->piv, piv, (size_t) n * sizeof(SlipPiv));
+    UP_(P->pinv.p_, pinv, (size_t) n * 4); UP_(P->row_perm.p_, rowperm, (size_t) n * 4); UP_(P->piv.p_, piv, (size_t) n * sizeof(SlipPiv));
     UP_(P->Lp, Lp, ((size_t) n + 1) * 8); UP_(P->Lo, Lo, ((size_t) n + 1) * 8); UP_(P->Li, Li, (size_t) lnz * 4); UP_(P->Le, Le, (size_t) lnz * sizeof(SlipEnt)); UP_(P->Llimbs, Llimbs, (size_t) lnl * 8);
     UP_(P->Up, Up, ((size_t) n + 1) * 8); UP_(P->Uo, Uo, ((size_t) n + 1) * 8); UP_(P->Ui, Ui, (size_t) unz * 4); UP_(P->Ue, Ue, (size_t) unz * sizeof(SlipEnt)); UP_(P->Ulimbs, Ulimbs, (size_t) unl * 8);
     if (!rc && (hipEventCreate(&f->ev0) != hipSuccess || hipEventCreate(&f->ev1) != hipSuccess)) rc = SLIP_HIP_DEVICE_ERROR;
@@ -1114,8 +1114,8 @@ extern "C" int slip_hip_factor_set_prefix(slip_hip_factor *f, int32_t K,
         P->Ucap_nz = nz; P->Ucap_nl = nl;
     }
 #define UP_(dst, src, bytes) do { if (!rc && (bytes) > 0 && hipMemcpy((void *)(dst), (src), (size_t)(bytes), hipMemcpyHostToDevice) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR; } while (0)
-    UP_(P->pinv, pinv, (size_t) n * 4); UP_(P->row_perm, rowperm, (size_t) n * 4); UP_(P->piv, piv, (size_t) K * sizeof(SlipPiv));
-    UP_(P->sw_row, swr, (size_t) K * 4); UP_(P->sw_pos, swp, (size_t) K * 4); UP_(P->Lready, ready, (size_t) K * 4);
+    UP_(P->pinv.p_, pinv, (size_t) n * 4); UP_(P->row_perm.p_, rowperm, (size_t) n * 4); UP_(P->piv.p_, piv, (size_t) K * sizeof(SlipPiv));
+    UP_(P->sw_row.p_, swr, (size_t) K * 4); UP_(P->sw_pos.p_, swp, (size_t) K * 4); UP_(P->Lready.p_, ready, (size_t) K * 4);
     UP_(P->Lp, Lp, ((size_t) K + 1) * 8); UP_(P->Lo, Lo, ((size_t) K + 1) * 8); UP_(P->Li, Li, (size_t) lnz * 4); UP_(P->Le, Le, (size_t) lnz * sizeof(SlipEnt)); UP_(P->Llimbs, Llimbs, (size_t) lnl * 8);
     UP_(P->Up, Up, ((size_t) K + 1) * 8); UP_(P->Uo, Uo, ((size_t) K + 1) * 8); UP_(P->Ui, Ui, (size_t) unz * 4); UP_(P->Ue, Ue, (size_t) unz * sizeof(SlipEnt)); UP_(P->Ulimbs, Ulimbs, (size_t) unl * 8);
     if (!rc) {
@@ -1316,7 +1316,7 @@ static int rescale_one(slip_hip_factor *f, int isL, int64_t nz, int64_t nl_alloc
     int rc = 0;
     if (hipMemcpy(he, isL ? P->Le : P->Ue, (size_t) nz * sizeof(SlipEnt), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(hidx, isL ? P->Li : P->Ui, (size_t) nz * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(hpinv, P->pinv, (size_t) f->n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(hpinv, P->pinv.p_, (size_t) f->n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(hp, isL ? P->Lp : P->Up, ((size_t) K + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
     /* lay the products out: digits(entry) + digits(scale) bound the product */
     int64_t o = 0;
@@ -1338,8 +1338,8 @@ static int rescale_one(slip_hip_factor *f, int isL, int64_t nz, int64_t nl_alloc
     if (!rc) {
         SlipRescaleArgs A; memset(&A, 0, sizeof A);
         A.ent = isL ? P->Le : P->Ue; A.limbs = isL ? P->Llimbs : P->Ulimbs; A.idx = isL ? P->Li : P->Ui; A.nz = nz;
-        A.colp = isL ? P->Lp : NULL; A.ncols = K; A.pinv = P->pinv;
-        A.slen = dslen; A.soff = dsoff; A.slimbs = dslimbs; A.oent = de; A.olimbs = dl; A.pividx = f->rspiv; A.row_perm = P->row_perm;
+        A.colp = isL ? P->Lp : NULL; A.ncols = K; A.pinv = P->pinv.p_;
+        A.slen = dslen; A.soff = dsoff; A.slimbs = dslimbs; A.oent = de; A.olimbs = dl; A.pividx = f->rspiv; A.row_perm = P->row_perm.p_;
 #ifndef SLIP_EMULATE
         int64_t blocks = (nz + 3) / 4; if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(slip_rescale_kernel, dim3((unsigned) blocks), dim3(256), 0, stream, A);
@@ -1587,12 +1587,12 @@ extern "C" int slip_hip_factor_download(const slip_hip_factor *f,
         if (L_limbs_inout) *L_limbs_inout = wl;
         if (U_limbs_inout) *U_limbs_inout = wu;
     }
-    if (pinv) CK(hipMemcpy(pinv, P->pinv, (size_t) f->n * 4, hipMemcpyDeviceToHost));
+    if (pinv) CK(hipMemcpy(pinv, P->pinv.p_, (size_t) f->n * 4, hipMemcpyDeviceToHost));
     if ((rholen || rholimbs) && K > 0) {
         /* the pivots live in the L slab: gather them through the pivot records (a rescaled copy: through the pivot entries) */
         SlipPiv *pr = (SlipPiv *) malloc((size_t) K * sizeof(SlipPiv));
         if (!pr) return SLIP_HIP_OUT_OF_MEMORY;
-        if (hipMemcpy(pr, P->piv, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(pr); return SLIP_HIP_DEVICE_ERROR; }
+        if (hipMemcpy(pr, P->piv.p_, (size_t) K * sizeof(SlipPiv), hipMemcpyDeviceToHost) != hipSuccess) { free(pr); return SLIP_HIP_DEVICE_ERROR; }
         const uint64_t *Lsrc = P->Llimbs;
         if (f->rescaled) {
             int64_t *pi = (int64_t *) malloc((size_t) K * 8);

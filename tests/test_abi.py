@@ -44,3 +44,20 @@ def test_product_fails_loudly_without_gpu():
 def test_missing_library_raises():
     with pytest.raises(OSError):
         _lib.load("/nonexistent/libslip_hip.so")
+
+
+def test_shared_arrays_cannot_be_dereferenced_plainly(tmp_path):
+    """cross-worker data is a distinct pointer type (slip_shared<T>, ref_lu_pipe.h): `P.pinv[i]` -- a load the compiler may keep
+    in a register, a store that never leaves the L1 -- does not compile; the accessor form does"""
+    import subprocess
+    csrc = os.path.join(ROOT, "slip_lu_amd", "csrc")
+    emu = os.path.join(ROOT, "tests", "emu")
+    head = '#include "hip_rt_emu.h"\n#include "fiber_emu.h"\n#include "ref_lu_pipe.h"\n'
+    good = head + "int f(const SlipParams &P) { return slip_ld_i32(P.pinv.at(3)) + slip_ld_i32(P.Lready.at(1)) + (int) slip_ld_u32(P.pkg.at() + 7); }\n"
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-DSLIP_EMULATE", "-I", emu, "-I", csrc, "-x", "c++"]
+    src = tmp_path / "good.cpp"; src.write_text(good)
+    assert subprocess.run(cmd + [str(src)], capture_output=True).returncode == 0
+    for expr in ("P.pinv[3]", "P.row_perm[0]", "P.piv[2].len", "P.Lready[1]", "*P.pkg", "P.jobs[0]", "P.invd[5]", "P.sw_row[0] + P.sw_pos[0]"):
+        bad = head + "int f(const SlipParams &P) { return (int) (%s); }\n" % expr
+        src = tmp_path / "bad.cpp"; src.write_text(bad)
+        assert subprocess.run(cmd + [str(src)], capture_output=True).returncode != 0, expr
