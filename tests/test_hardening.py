@@ -131,7 +131,7 @@ def test_create_rejects_dimensions_beyond_the_protocol_fields(emu_lib):
     assert rc == -3 and not h.value
 
 
-@pytest.mark.parametrize("name,K", [("gen_n40", 15), ("gen_n40", 40), ("gen_n40", 0), ("test_mat_p4tol", 4), ("10teams", 60)])
+@pytest.mark.parametrize("name,K", [("gen_n40", 15), ("test_mat", 10), ("test_mat", 0), ("test_mat_p4tol", 4), ("10teams", 60)])
 def test_continue_from_a_given_prefix(emu_lib, name, K):
     """slip_hip_factor_set_prefix: the first K columns are given (here: taken from a run that stopped at K), the handle goes
     on from column K and ends with the reference's factors -- SLIP_LU_factorize.c:190-264 entered at k = K"""
