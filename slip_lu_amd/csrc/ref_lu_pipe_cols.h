@@ -790,7 +790,7 @@ SLIP_DEV void slip_takeover_full(const SlipParams &P, const int k, const int tag
  * otherwise the generic build picks either place at run time (flat addressing). */
 template <bool FAST>
 SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, const int tag, uint32_t *lds,
-                            unsigned long long *acc)
+                            unsigned long long *acc_unused = (unsigned long long *) 0)
 {
     const int tid = slip_tid(), T = slip_nthreads(), lane = slip_lane(), wave = slip_wave(), nw = slip_nwaves();
     const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
@@ -1996,7 +1996,23 @@ SLIP_DEV int slip_do_column(const SlipParams &P, SlipState *st, const int k, con
         slip_agent_add_u64((unsigned long long *) &st->Unl_exact, totU);
         slip_agent_max_u64(&st->c_maxdig, (unsigned long long) maxdig);
     }
-    acc[0] += c_read; acc[1] += c_upd; acc[2] += c_src; acc[3] += c_str; acc[4] += c_mac;
+    /* this column's counters go to the launch totals now, wave by wave (they used to ride in ten registers per lane from
+     * column to column, in a kernel whose register allocation is at the limit) */
+    {
+        auto wsum64 = [&](unsigned long long v) -> unsigned long long {
+            const unsigned long long a = slip_wave_sum_u32((uint32_t)(v & 0xFFFFFFull)), b = slip_wave_sum_u32((uint32_t)((v >> 24) & 0xFFFFFFull));
+            const unsigned long long c = slip_wave_sum_u32((uint32_t)(v >> 48));
+            return a + (b << 24) + (c << 48);
+        };
+        const unsigned long long t_read = wsum64(c_read), t_upd = wsum64(c_upd), t_src = wsum64(c_src), t_str = wsum64(c_str), t_mac = wsum64(c_mac);
+        if (lane == 0) {
+            if (t_read) slip_agent_add_u64(&st->c_read, t_read);
+            if (t_upd) slip_agent_add_u64(&st->c_upd, t_upd);
+            if (t_src) slip_agent_add_u64(&st->c_src, t_src);
+            if (t_str) slip_agent_add_u64(&st->c_streamed, t_str);
+            if (t_mac) slip_agent_add_u64(&st->c_macs, t_mac);
+        }
+    }
 #ifdef SLIP_PROFILING
     if (tid == 0) P.dbg[18 * (int64_t) P.n + 6 * (int64_t) k + 4] = (int32_t) slip_realtime();          /* time line 4: the column ends */
     if (tid == 0) P.dbg[17 * (int64_t) P.n + k] |= (packaged ? 1 : 0) | (adopted ? 2 : 0) | (fastc ? 4 : 0) | (early ? 8 : 0) | (sv[SV_PKGVER] << 4) | (nrows << 16);
@@ -2014,7 +2030,6 @@ SLIP_DEV void slip_factor_worker(const SlipParams &P, SlipState *st, uint32_t *l
     const int tid = slip_tid();
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     uint64_t *scan_tmp = (uint64_t *)(lds + SLIP_LDS_SCAN);
-    unsigned long long acc[5] = {0, 0, 0, 0, 0};
     if (tid == 0) { sv[SV_CUP] = 0; sv[SV_NOENG] = 0; }     /* the committer has not been seen yet */
     for (;;) {
         slip_block_sync();
@@ -2028,24 +2043,13 @@ SLIP_DEV void slip_factor_worker(const SlipParams &P, SlipState *st, uint32_t *l
         slip_block_sync();
         const int k = sv[SV_K], tag = sv[SV_TAG];
         if (k >= P.k_stop) break;
-        const int status = slip_do_column<FAST>(P, st, k, tag, lds, acc);
+        const int status = slip_do_column<FAST>(P, st, k, tag, lds);
         if (status == SLIPDEV_OK) continue;
         if (status != SLIPDEV_ABORTED && tid == 0) slip_raise_stop(st, status == SLIPDEV_INTERNAL ? 0 : k, status);
         break;
     }
     slip_block_sync();
-    /* per-thread counters of the committed columns -> totals */
-    unsigned long long v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    slip_block_sum4(v, scan_tmp);
-    unsigned long long w[4] = {acc[4], 0, 0, 0};
-    slip_block_sum4(w, scan_tmp);
-    if (tid == 0) {
-        if (v[0]) slip_agent_add_u64(&st->c_read, v[0]);
-        if (v[1]) slip_agent_add_u64(&st->c_upd, v[1]);
-        if (v[2]) slip_agent_add_u64(&st->c_src, v[2]);
-        if (v[3]) slip_agent_add_u64(&st->c_streamed, v[3]);
-        if (w[0]) slip_agent_add_u64(&st->c_macs, w[0]);
-    }
+    (void) scan_tmp;
 }
 
 /* ------------------------------------------------------------------ */
