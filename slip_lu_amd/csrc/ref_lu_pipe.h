@@ -1218,8 +1218,8 @@ SLIP_DEV int slip_farm_items(const SlipParams &P, uint32_t *jb, int kind, int j,
         if (slip_lane() == 0) t = slip_agent_add_i32((int32_t *)(jb + 16), 1);
         t = (int) slip_bcast0_u32((uint32_t) t);
         if (t >= nq) break;
-        uint32_t it0, it1;                       /* kind 1: (entry, row) pairs; kind 2: rows */
-        if (kind == 1) {
+        uint32_t it0, it1;                       /* kinds 1 and 5: (entry, row) pairs; kind 2: rows */
+        if (kind == 1 || kind == 5) {
             if (wl) { it0 = wl[2 * t]; it1 = wl[2 * t + 1]; }
             else { it0 = slip_ld_u32(jb + 32 + 2 * t); it1 = slip_ld_u32(jb + 32 + 2 * t + 1); }
         } else { it0 = wl ? wl[t] : slip_ld_u32(jb + 32 + t); it1 = 0u; }
@@ -1293,25 +1293,26 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     /* (only a column whose turn is near: further away the worker has the time, and every helper costs its XCD an L2 write-back
      * and invalidate) */
-    if (P.farm && (kind == 1 || (kind == 2 && SLIP_FARM_KIND2)) && nq >= SLIP_FARM_MIN_ITEMS && !sv[SV_ERR]) {
+    if (P.farm && (kind == 1 || kind == 5 || (kind == 2 && SLIP_FARM_KIND2)) && nq >= SLIP_FARM_MIN_ITEMS && !sv[SV_ERR]) {
         /* kind 2: the rows of a committed column that still need their division (its readers wait for its stage 2).  The
          * protocol carries them and a 700-row column of the C4 window then takes 0.35 ms instead of 1.5 -- but the window as a
          * whole got slower (median 6.37 against 6.06 ms over 30 runs: every helper costs its XCD an L2 invalidate), so: off */
-        const int lr = slip_limbs(slip_ld_piv(P.piv.at(kind == 1 ? jn : k - 1)).len);
+        /* (kind 5, back substitution: the multiplier is x[j]; the solves have no frontier, every long queue is opened) */
+        const int lr = kind == 5 ? slip_limbs(P.xrow[j].len) : slip_limbs(slip_ld_piv(P.piv.at(kind == 1 ? jn : k - 1)).len);
         /* the queue alone takes about nq * 8 lr^2 / waves cycles; the frontier moves a column every few microseconds */
         const int64_t cost = (int64_t) nq * lr * lr;
-        if (cost >= (kind == 2 ? (int64_t) SLIP_FARM_KIND2_COST : (int64_t) SLIP_FARM_MIN_COST) && (kind == 2 || SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
+        if (cost >= (kind == 2 ? (int64_t) SLIP_FARM_KIND2_COST : (int64_t) SLIP_FARM_MIN_COST) && (kind == 2 || kind == 5 || !P.in_factor || SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
             /* a long queue of long updates: open it to the workers that are waiting */
             const int tid = slip_tid(), T = slip_nthreads();
             uint32_t *jb = P.jobs.at() + (int64_t) P.worker * SLIP_JOB_WORDS;
-            for (int c = tid; c < (kind == 1 ? 2 * nq : nq); c += T) slip_st_u32(jb + 32 + c, wl[c]);
+            for (int c = tid; c < ((kind == 1 || kind == 5) ? 2 * nq : nq); c += T) slip_st_u32(jb + 32 + c, wl[c]);
             if (tid == 0) {
                 slip_st_u32(jb + 2, (uint32_t) kind); slip_st_u32(jb + 3, (uint32_t) j); slip_st_u32(jb + 4, (uint32_t) jn); slip_st_u32(jb + 5, (uint32_t) k);
                 slip_st_u64((uint64_t *)(jb + 6), (uint64_t) m0); slip_st_u32(jb + 8, (uint32_t) nq); slip_st_u32(jb + 11, 0u); slip_st_u32(jb + 16, 0u);
             }
             slip_vm_drain();
             slip_block_sync();
-            if (tid == 0) { slip_agent_release(); slip_agent_add_i32((int32_t *) jb, 1); slip_st_i32(&P.st->farm_hint[P.worker & 7], kind == 1 ? P.worker + 1 : -(P.worker + 1)); slip_agent_add_u64(&P.st->c_farm, 1ull); }
+            if (tid == 0) { slip_agent_release(); slip_agent_add_i32((int32_t *) jb, 1); slip_st_i32(&P.st->farm_hint[P.worker & 7], kind != 2 ? P.worker + 1 : -(P.worker + 1)); slip_agent_add_u64(&P.st->c_farm, 1ull); }
             const int e = slip_farm_items(P, jb, kind, j, jn, k, m0, nq, wl, b0, b1, b2);
             if (e && lane == 0) sv[SV_ERR] = e;
             slip_vm_drain();

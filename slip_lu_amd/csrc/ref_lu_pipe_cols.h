@@ -2257,11 +2257,14 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
 
 /* kernel body of the solves: every workgroup draws right-hand sides from the ticket counter (they are independent,
  * slip_forward_sub.c:61-158 per column of b); rhs_done[c] marks the finished ones so that a relaunch after a grow
- * only repeats the others */
+ * only repeats the others.  A workgroup that draws no right-hand side HELPS (round 3): a single right-hand side is one
+ * chain of n source steps on one workgroup, and the long update queues of its heavy steps (slip_drain opens them exactly
+ * as in the factorisation: kind 1 forward, kind 5 backward) are taken by the waves of the helpers.  st->exited counts the
+ * right-hand sides that are through; the helpers leave when it reaches nrhs. */
 template <bool FAST>
 SLIP_DEV void slip_solve_worker(const SlipParams &P, SlipState *st, const SlipSolveArgs &A, int32_t *rhs_done, uint32_t *lds)
 {
-    const int tid = slip_tid();
+    const int tid = slip_tid(), wave = slip_wave();
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     for (;;) {
         slip_block_sync();
@@ -2272,12 +2275,35 @@ SLIP_DEV void slip_solve_worker(const SlipParams &P, SlipState *st, const SlipSo
         slip_block_sync();
         const int c = sv[SV_K], tag = sv[SV_TAG];
         if (c >= A.nrhs) break;
-        if (rhs_done[c]) continue;
-        const int status = slip_solve_rhs<FAST>(P, st, A, c, tag, lds);
-        if (tid == 0) {
-            if (status == SLIPDEV_OK) rhs_done[c] = 1;
-            else slip_raise_stop(st, c, status);
+        if (!rhs_done[c]) {
+            const int status = slip_solve_rhs<FAST>(P, st, A, c, tag, lds);
+            if (tid == 0) {
+                if (status == SLIPDEV_OK) rhs_done[c] = 1;
+                else slip_raise_stop(st, c, status);
+            }
         }
+        if (tid == 0) slip_agent_add_i32(&st->exited, 1);
+    }
+    if (!P.farm) return;
+    /* no right-hand side left for this workgroup: help until the last one is through */
+    const bool BM_LDS = FAST || P.bitmap_in_lds, SCR_LDS = FAST || P.scratch_in_lds;
+    const int wcap = P.wcap;
+    dig_t *b0 = SCR_LDS ? lds + SLIP_LDS_BITMAP + (BM_LDS ? P.bm_words : 0) + wave * 3 * wcap
+                        : P.gscratch + (int64_t) wave * 3 * wcap;
+    dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
+    unsigned long long spins = 0;
+    for (;;) {
+        slip_block_sync();
+        if (tid == 0) {
+            int s_ = slip_ld_i32(&st->exited) >= A.nrhs ? -1 : slip_farm_peek(P, st);
+            if (++spins > SLIP_SPIN_LIMIT) s_ = -1;
+            sv[SV_TMP3] = s_;
+        }
+        slip_block_sync();
+        const int s_ = sv[SV_TMP3];
+        if (s_ < 0) break;
+        if (s_ > 0) slip_farm_help(P, st, lds, s_ - 1, b0, b1, b2);
+        else slip_sleep();
     }
 }
 

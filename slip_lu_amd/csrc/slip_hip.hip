@@ -1136,16 +1136,28 @@ extern "C" int slip_hip_factor_set_prefix(slip_hip_factor *f, int32_t K,
 }
 
 /* ---- REF triangular solves on the resident factors (SLIP_LU_solve.c:41-86) ---- */
+#ifndef SLIP_SOLVE_HELPERS
+#define SLIP_SOLVE_HELPERS 16
+#endif
 static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, int32_t *rhs_done, hipStream_t stream)
 {
     f->P.t0 = f->hs.ticket;
     f->hs.stop = INT64_MAX; f->hs.exited = 0;
     f->P.farm = 0; f->P.committer = 0; f->P.st = f->ds; f->P.in_factor = 0;
+    for (int q_ = 0; q_ < 8; q_++) f->hs.farm_hint[q_] = 0;
     { const int e = upload_state(f, stream); if (e) return e; }
+    /* one workgroup per right-hand side in flight; with fewer right-hand sides than workgroups, up to SLIP_SOLVE_HELPERS more
+     * that only help with the long update queues (ref_lu_pipe_cols.h: slip_solve_worker) */
     int32_t W = f->nworkers;
-    if (W > A.nrhs) W = A.nrhs;
+    if (W > A.nrhs) {
+        int32_t H = f->no_farm || !f->P.jobs.p_ ? 0 : SLIP_SOLVE_HELPERS;
+        if (A.nrhs + H > W) H = W - A.nrhs;
+        W = A.nrhs + H;
+        f->P.farm = H > 0;
+    }
     if (W < 1) W = 1;
     f->P.nworkers = W;
+    if (f->P.farm) CK(hipMemsetAsync(f->P.jobs.p_, 0, (size_t) W * SLIP_JOB_WORDS * 4, stream));
     CK(hipEventRecord(f->ev0, stream));
 #ifndef SLIP_EMULATE
     const size_t lds_bytes = (size_t) f->lds_words * 4;

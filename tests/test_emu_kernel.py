@@ -98,6 +98,16 @@ def test_emulated_solve_matches_reference(emu_lib, name, waves, workers, nrhs):
     check_solve(case, lib_path=emu_lib, nrhs=nrhs, waves=waves, workers=workers)
 
 
+@pytest.mark.parametrize("name,waves,workers,nrhs", [("solve_gen_n40", 2, 5, 1), ("solve_test_mat", 1, 4, 2)])
+def test_emulated_solve_with_helpers(emu_farm_lib, name, waves, workers, nrhs):
+    """fewer right-hand sides than workgroups: the others help with the update queues of the substitutions (forward: kind 1,
+    backward: kind 5; the build that opens every queue of two or more items), same numerators"""
+    import json
+    from conftest import GOLDEN, check_solve
+    case = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "solve_index.json")))}[name]
+    check_solve(case, lib_path=emu_farm_lib, nrhs=nrhs, waves=waves, workers=workers)
+
+
 def test_emulated_solve_zero_and_unit_rhs(emu_lib):
     import json
     import numpy as np
