@@ -2071,6 +2071,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
     dig_t *b1 = b0 + wcap, *b2 = b1 + wcap;
     unsigned long long c_read = 0, c_upd = 0, c_src = 0, c_str = 0, c_mac = 0;
 
+    if (tid == 0 && c == 0) P.dbg[24 * (int64_t) P.n + 3072 + 0] = (int32_t) slip_realtime();      /* solve time line (diagnostic words) */
     /* b2[pinv[i]] = b[i]  (SLIP_LU_solve.c:68-75): rows keep their ids, the bitmap is indexed by position */
     for (int w = tid; w < P.bm_words; w += T) bm[w] = 0;
     if (tid == 0) { sv[SV_ERR] = 0; sv[SV_CNT0] = 0; sv[SV_CNT0 + 1] = 0; sv[SV_CNT0 + 2] = 0; sv[SV_NROWS] = 0; sv[SV_F] = n; }
@@ -2095,12 +2096,14 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
     slip_block_sync();
     if (sv[SV_ERR]) return SLIPDEV_GROW_X;
 
+    if (tid == 0 && c == 0) P.dbg[24 * (int64_t) P.n + 3072 + 1] = (int32_t) slip_realtime();      /* solve time line (diagnostic words) */
     /* forward substitution = the sweep over ALL pivot positions (slip_forward_sub.c:61-158) */
     unsigned long long tw_[3] = {0, 0, 0}, tl_ = 0;
     slip_sweep<FAST, false>(P, st, n, tag, lds, bm, b0, b1, b2, c_read, c_upd, c_src, c_str, c_mac, tw_, &tl_);
     slip_block_sync();
     if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
 
+    if (tid == 0 && c == 0) P.dbg[24 * (int64_t) P.n + 3072 + 2] = (int32_t) slip_realtime();      /* solve time line (diagnostic words) */
     /* x <- x * det (slip_array_mul.c:19), det = rho[n-1] */
     int npat, nUdummy;
     slip_pattern(P, lds, bm, n, &npat, &nUdummy);
@@ -2143,6 +2146,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
     }
     if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
 
+    if (tid == 0 && c == 0) P.dbg[24 * (int64_t) P.n + 3072 + 3] = (int32_t) slip_realtime();      /* solve time line (diagnostic words) */
     /* back substitution (slip_back_sub.c:36-52): positions descending; x_j /= U_jj (= rho_j, the last entry
      * of U(:,j)), then x_i -= U_ij x_j for the rows above */
     {
@@ -2225,6 +2229,7 @@ SLIP_DEV int slip_solve_rhs(const SlipParams &P, SlipState *st, const SlipSolveA
     slip_block_sync();
     if (sv[SV_ERR]) return sv[SV_ERR] >= 6 ? sv[SV_ERR] : SLIPDEV_GROW_X;
 
+    if (tid == 0 && c == 0) P.dbg[24 * (int64_t) P.n + 3072 + 4] = (int32_t) slip_realtime();      /* solve time line (diagnostic words) */
     /* output: numerators in pivot-position order (the order SLIP_LU_solve returns before SLIP_permute_x); every
      * right-hand side owns a region of the output slab */
     {

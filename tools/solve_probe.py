@@ -16,9 +16,16 @@ for name in sys.argv[1].split(","):
     x1 = g.solve(bl, bx); x1 = g.solve(bl, bx)
     t1 = g.solve_ms()
     i = g.info()
+    import ctypes as C
+    w = np.zeros(8, np.int32)
+    g.lib.slip_hip_factor_debug_words.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    phases = None
+    if g.lib.slip_hip_factor_debug_words(g.h, 24 * e["n"] + 3072, 8, w.ctypes.data) == 0 and w[4]:
+        d = [((int(w[q + 1]) - int(w[q])) & 0xFFFFFFFF) / 100.0 for q in range(4)]
+        phases = dict(scatter_us=round(d[0], 1), forward_us=round(d[1], 1), times_det_us=round(d[2], 1), backward_us=round(d[3], 1))
     bl16 = np.tile(bl, 16); bx16 = np.tile(bx, 16)
     x16 = g.solve(bl16, bx16, nrhs=16)
     t16 = g.solve_ms()
     same = np.array_equal(x16[0][:e["n"]], x1[0]) and np.array_equal(x16[0][-e["n"]:], x1[0])
-    print(json.dumps(dict(case=name, n=e["n"], solve_ms=round(t1, 3), solve16_ms=round(t16, 3), farm_jobs=i.get("farm_jobs"), farm_items=i.get("farm_items"), same=bool(same))), flush=True)
+    print(json.dumps(dict(case=name, n=e["n"], solve_ms=round(t1, 3), solve16_ms=round(t16, 3), farm_jobs=i.get("farm_jobs"), farm_items=i.get("farm_items"), same=bool(same), phases=phases)), flush=True)
     g.close()
