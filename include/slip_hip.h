@@ -163,6 +163,10 @@ int slip_hip_factor_set_prefix(slip_hip_factor *f, int32_t K,
                                const int32_t *piv_row);
 
 void slip_hip_factor_destroy(slip_hip_factor *f);
+/* Device buffers of destroyed handles are kept in a process-level pool for the next handle (the drop-in SLIP_LU_factorize
+ * creates and destroys one per call): at most SLIP_HIP_POOL_MB megabytes (environment, default 32768; 0 = no pool).  This
+ * gives them all back to the runtime. */
+void slip_hip_pool_release(void);
 
 /* Triplet files <-> limb slabs, host only.  read: what SLIP_tripread + SLIP_build_sparse_trip_mpz
  * produce (SLIP_LU/Demo/demos.c:245-331, SLIP_LU/Source/slip_trip_to_mat.c:23-69: "m n nz" then nz lines "i j value",

@@ -34,7 +34,7 @@ EXPORTS = ("slip_hip_default_options", "slip_hip_device_count", "slip_hip_factor
            "slip_hip_factor_download", "slip_hip_factor_destroy", "slip_hip_matgen",
            "slip_hip_free", "slip_hip_wave_op_test", "slip_hip_version",
            "slip_hip_factor_phase_cycles", "slip_hip_factor_solve", "slip_hip_factor_solve_ms",
-           "slip_hip_factor_from_factors", "slip_hip_factor_rescale", "slip_hip_factor_set_prefix", "slip_hip_read_triplet", "slip_hip_write_triplet")
+           "slip_hip_factor_from_factors", "slip_hip_factor_rescale", "slip_hip_factor_set_prefix", "slip_hip_pool_release", "slip_hip_read_triplet", "slip_hip_write_triplet")
 
 _libs = {}
 

@@ -316,10 +316,76 @@ struct slip_hip_factor {
 
 static void rescale_drop(slip_hip_factor *f);
 
+/* Device buffers go through a process-level pool: the drop-in SLIP_LU_factorize creates and destroys a
+ * handle per call, and a handle's private row arrays are gigabytes -- hipMalloc / hipFree of those cost milliseconds each.
+ * A freed buffer of at least 1 MiB is kept (up to SLIP_HIP_POOL_MB megabytes in all, default 32 768; 0 switches the pool off)
+ * and handed to the next request it fits within a quarter of its size.  Nothing relies on fresh memory being zero: every
+ * array that must start cleared is cleared where it is allocated or at reset.  Handles are destroyed after their streams
+ * have been synchronised (run / solve return synchronised), so a pooled buffer is never still in use. */
+#include <mutex>
+#include <unordered_map>
+struct SlipPoolEnt { void *p; size_t bytes; };
+static std::mutex slip_pool_mu;
+static std::vector<SlipPoolEnt> slip_pool;
+static std::unordered_map<void *, size_t> slip_pool_live;
+static size_t slip_pool_bytes = 0;
+static size_t slip_pool_limit(void)
+{
+    static long long mb = -1;
+    if (mb < 0) { const char *e = getenv("SLIP_HIP_POOL_MB"); mb = e ? atoll(e) : 32768; if (mb < 0) mb = 0; }
+    return (size_t) mb << 20;
+}
+static int dev_malloc_bytes(void **q, size_t bytes)
+{
+    {
+        std::lock_guard<std::mutex> g(slip_pool_mu);
+        size_t best = (size_t) -1, at = 0;
+        for (size_t t = 0; t < slip_pool.size(); t++)
+            if (slip_pool[t].bytes >= bytes && slip_pool[t].bytes - bytes <= bytes / 4 && slip_pool[t].bytes < best) { best = slip_pool[t].bytes; at = t; }
+        if (best != (size_t) -1) {
+            *q = slip_pool[at].p; slip_pool_live[*q] = best; slip_pool_bytes -= best;
+            slip_pool[at] = slip_pool.back(); slip_pool.pop_back();
+            return 0;
+        }
+    }
+    if (hipMalloc(q, bytes) != hipSuccess) {
+        /* the pool may be what is in the way: give it back and try once more */
+        std::vector<SlipPoolEnt> drop;
+        { std::lock_guard<std::mutex> g(slip_pool_mu); drop.swap(slip_pool); slip_pool_bytes = 0; }
+        for (const SlipPoolEnt &e : drop) hipFree(e.p);
+        if (drop.empty() || hipMalloc(q, bytes) != hipSuccess) return SLIP_HIP_OUT_OF_MEMORY;
+    }
+    std::lock_guard<std::mutex> g(slip_pool_mu);
+    slip_pool_live[*q] = bytes;
+    return 0;
+}
+static void dev_free(void *p)
+{
+    if (!p) return;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> g(slip_pool_mu);
+        auto it = slip_pool_live.find(p);
+        if (it != slip_pool_live.end()) { bytes = it->second; slip_pool_live.erase(it); }
+        if (bytes >= ((size_t) 1 << 20) && slip_pool_bytes + bytes <= slip_pool_limit()) {
+            slip_pool.push_back(SlipPoolEnt{p, bytes}); slip_pool_bytes += bytes;
+            return;
+        }
+    }
+    hipFree(p);
+}
+/* give every pooled buffer back to the runtime (tests; a host that wants the memory) */
+extern "C" void slip_hip_pool_release(void)
+{
+    std::vector<SlipPoolEnt> drop;
+    { std::lock_guard<std::mutex> g(slip_pool_mu); drop.swap(slip_pool); slip_pool_bytes = 0; }
+    for (const SlipPoolEnt &e : drop) hipFree(e.p);
+}
+
 template <class T> static int dev_alloc(T **p, int64_t count)
 {
     void *q = NULL;
-    if (hipMalloc(&q, (size_t)(count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return SLIP_HIP_OUT_OF_MEMORY;
+    if (dev_malloc_bytes(&q, (size_t)(count > 0 ? count : 1) * sizeof(T))) return SLIP_HIP_OUT_OF_MEMORY;
     *p = (T *) q;
     return 0;
 }
@@ -327,8 +393,8 @@ template <class T> static int dev_grow(T **p, int64_t old_count, int64_t new_cou
 {
     T *q = NULL;
     if (dev_alloc(&q, new_count)) return SLIP_HIP_OUT_OF_MEMORY;
-    if (old_count > 0 && hipMemcpy(q, *p, (size_t) old_count * sizeof(T), hipMemcpyDeviceToDevice) != hipSuccess) { hipFree(q); return SLIP_HIP_DEVICE_ERROR; }
-    hipFree(*p);
+    if (old_count > 0 && hipMemcpy(q, *p, (size_t) old_count * sizeof(T), hipMemcpyDeviceToDevice) != hipSuccess) { dev_free(q); return SLIP_HIP_DEVICE_ERROR; }
+    dev_free(*p);
     *p = q;
     return 0;
 }
@@ -583,17 +649,17 @@ static int alloc_x(slip_hip_factor *f, int32_t xcap, int keep_rows)
     }
     if (rc) {
         /* nothing of the handle has been touched: it stays usable at the old stride */
-        hipFree(nxd); hipFree(ninvd); hipFree(ngs); hipFree(ngb); hipFree(nxrow); hipFree(npat); hipFree(nrlist); hipFree(nrpos); hipFree(nsrow); hipFree(npkg); hipFree(njobs);
+        dev_free(nxd); dev_free(ninvd); dev_free(ngs); dev_free(ngb); dev_free(nxrow); dev_free(npat); dev_free(nrlist); dev_free(nrpos); dev_free(nsrow); dev_free(npkg); dev_free(njobs);
         if (old_xcap > 0) { P->xcap = old_xcap; P->invcap = old_invcap; f->waves = old_waves; plan_launch(f); }
         return rc;
     }
-    hipFree(P->xd); hipFree(P->invd.p_); hipFree(P->gscratch); hipFree(P->gbitmap);
+    dev_free(P->xd); dev_free(P->invd.p_); dev_free(P->gscratch); dev_free(P->gbitmap);
     P->xd = nxd; P->invd.p_ = ninvd; P->gscratch = ngs; P->gbitmap = ngb;
     if (!keep_rows) {
-        hipFree(P->xrow); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow);
+        dev_free(P->xrow); dev_free(P->pat); dev_free(P->rlist); dev_free(P->rpos); dev_free(P->srow);
         P->xrow = nxrow; P->pat = npat; P->rlist = nrlist; P->rpos = nrpos; P->srow = nsrow;
     }
-    if (npkg) { hipFree(P->pkg.p_); hipFree(P->jobs.p_); P->pkg.p_ = npkg; P->jobs.p_ = njobs; }
+    if (npkg) { dev_free(P->pkg.p_); dev_free(P->jobs.p_); P->pkg.p_ = npkg; P->jobs.p_ = njobs; }
     f->nworkers = W32; P->nworkers = W32; P->priv_rows = n;
     return 0;
 }
@@ -638,13 +704,13 @@ extern "C" void slip_hip_factor_destroy(slip_hip_factor *f)
 {
     if (!f) return;
     SlipParams *P = &f->P;
-    hipFree(f->dAp); hipFree(f->dAi); hipFree(f->dAlen); hipFree(f->dAoff); hipFree(f->dAlimbs); hipFree(f->dq);
-    hipFree(P->pinv.p_); hipFree(P->row_perm.p_); hipFree(P->xrow); hipFree(P->xd);
-    hipFree(P->piv.p_); hipFree(P->invd.p_);
-    hipFree(P->Lp); hipFree(P->Lo); hipFree(P->Li); hipFree(P->Le); hipFree(P->Llimbs);
-    hipFree(P->Up); hipFree(P->Uo); hipFree(P->Ui); hipFree(P->Ue); hipFree(P->Ulimbs);
-    hipFree(P->Lready.p_); hipFree(P->pat); hipFree(P->rlist); hipFree(P->rpos); hipFree(P->srow); hipFree(P->gscratch); hipFree(P->gbitmap); hipFree(P->dbg); hipFree(P->pkg.p_); hipFree(P->jobs.p_); hipFree(P->sw_row.p_); hipFree(P->sw_pos.p_);
-    hipFree(f->ds); hipFree(f->ident);
+    dev_free(f->dAp); dev_free(f->dAi); dev_free(f->dAlen); dev_free(f->dAoff); dev_free(f->dAlimbs); dev_free(f->dq);
+    dev_free(P->pinv.p_); dev_free(P->row_perm.p_); dev_free(P->xrow); dev_free(P->xd);
+    dev_free(P->piv.p_); dev_free(P->invd.p_);
+    dev_free(P->Lp); dev_free(P->Lo); dev_free(P->Li); dev_free(P->Le); dev_free(P->Llimbs);
+    dev_free(P->Up); dev_free(P->Uo); dev_free(P->Ui); dev_free(P->Ue); dev_free(P->Ulimbs);
+    dev_free(P->Lready.p_); dev_free(P->pat); dev_free(P->rlist); dev_free(P->rpos); dev_free(P->srow); dev_free(P->gscratch); dev_free(P->gbitmap); dev_free(P->dbg); dev_free(P->pkg.p_); dev_free(P->jobs.p_); dev_free(P->sw_row.p_); dev_free(P->sw_pos.p_);
+    dev_free(f->ds); dev_free(f->ident);
     rescale_drop(f);
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
@@ -1262,7 +1328,7 @@ extern "C" int slip_hip_factor_solve(slip_hip_factor *f, int32_t nrhs, const int
             if (status == SLIPDEV_GROW_X) rc = grow_x_keep(f, (int64_t) P->xcap * 2, n);
             else if (status == SLIPDEV_GROW_U) {
                 /* the output regions: twice the stride; finished right-hand sides are simply solved again */
-                hipFree(dol); dol = NULL;
+                dev_free(dol); dol = NULL;
                 ostride *= 2;
                 rc = dev_alloc(&dol, ostride * nrhs);
                 if (!rc && hipMemset(ddone, 0, (size_t) nrhs * 4) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
@@ -1302,7 +1368,7 @@ extern "C" int slip_hip_factor_solve(slip_hip_factor *f, int32_t nrhs, const int
         }
     }
     free(xl); free(xlimbs); free(hlen); free(hoff); free(hdone); free(raw); free(hooff);
-    hipFree(dblen); hipFree(dboff); hipFree(dbl); hipFree(dolen); hipFree(dooff); hipFree(dol); hipFree(ddone);
+    dev_free(dblen); dev_free(dboff); dev_free(dbl); dev_free(dolen); dev_free(dooff); dev_free(dol); dev_free(ddone);
     return rc;
 }
 
@@ -1311,7 +1377,7 @@ extern "C" double slip_hip_factor_solve_ms(const slip_hip_factor *f) { return f 
 /* ---- subtree farm: multiply the committed factors by per-column scales ---- */
 static void rescale_drop(slip_hip_factor *f)
 {
-    hipFree(f->rsLe); hipFree(f->rsUe); hipFree(f->rsLl); hipFree(f->rsUl); hipFree(f->rspiv);
+    dev_free(f->rsLe); dev_free(f->rsUe); dev_free(f->rsLl); dev_free(f->rsUl); dev_free(f->rspiv);
     f->rsLe = f->rsUe = NULL; f->rsLl = f->rsUl = NULL; f->rspiv = NULL; f->rescaled = 0;
 }
 
@@ -1365,8 +1431,8 @@ static int rescale_one(slip_hip_factor *f, int isL, int64_t nz, int64_t nl_alloc
         else     { f->rsUe = de; f->rsUl = dl; f->rsUnl = o; }
         de = NULL; dl = NULL;
     }
-    if (de) hipFree(de);
-    if (dl) hipFree(dl);
+    if (de) dev_free(de);
+    if (dl) dev_free(dl);
     (void) nl_alloc;
     free(he); free(hidx); free(hpinv); free(hp);
     return rc;
@@ -1419,7 +1485,7 @@ extern "C" int slip_hip_factor_rescale(slip_hip_factor *f, int32_t nscales, cons
         if (!rc) f->rescaled = 1;
     }
     if (rc) rescale_drop(f);
-    hipFree(dslen); hipFree(dsoff); hipFree(dsl);
+    dev_free(dslen); dev_free(dsoff); dev_free(dsl);
     free(hd); free(habs); free(ho);
     return rc;
 }
@@ -1547,8 +1613,8 @@ static int fetch_factor(int32_t *len_out, uint64_t *limbs_out, const SlipEnt *de
             hipLaunchKernelGGL(slip_gather_kernel, dim3((unsigned) blocks), dim3(256), 0, 0, dev_ent, dev_limbs, d_ooff, d_out, nz);
             if (hipGetLastError() != hipSuccess || hipMemcpy(limbs_out, d_out, (size_t) total * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SLIP_HIP_DEVICE_ERROR;
         }
-        if (d_ooff) hipFree(d_ooff);
-        if (d_out) hipFree(d_out);
+        if (d_ooff) dev_free(d_ooff);
+        if (d_out) dev_free(d_out);
         free(ooff);
 #else
         uint64_t *raw = (uint64_t *) malloc((size_t)(nl_alloc > 0 ? nl_alloc : 1) * 8);
@@ -1668,7 +1734,7 @@ extern "C" int slip_hip_wave_op_test(int32_t op, int32_t nops, int32_t la, int32
 #endif
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(out, dout, (size_t) nops * W * 4, hipMemcpyDeviceToHost));
-    hipFree(da); hipFree(db); hipFree(dout); hipFree(ds);
+    dev_free(da); dev_free(db); dev_free(dout); dev_free(ds);
     return SLIP_HIP_OK;
 }
 
@@ -1688,7 +1754,7 @@ extern "C" int slip_hip_wave_op_bench(int32_t op, int32_t la, int32_t lb, int32_
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(cycles_out, dc, (size_t) nwaves * 8, hipMemcpyDeviceToHost));
-    hipFree(da); hipFree(db); hipFree(dout); hipFree(dc);
+    dev_free(da); dev_free(db); dev_free(dout); dev_free(dc);
     return SLIP_HIP_OK;
 }
 #endif

@@ -155,3 +155,13 @@ def test_gpu_farm_complete():
     got = parallel.farm_complete(None, n, Ap, Ai, Ax, q, n0)
     assert got["farm_prefix"] == n0 and got["K"] == n
     T.same_factors(got, whole)
+
+
+def test_gpu_handles_reuse_pooled_buffers():
+    """create -> run -> destroy cycles (what the drop-in SLIP_LU_factorize does per call) on buffers taken from the process-level
+    pool: every cycle ends with the reference's factors (nothing relies on fresh device memory), and the pool can be given back"""
+    from slip_lu_amd import _lib
+    for name in ("gen_n2000_pm1", "10teams", "gen_n2000_pm1", "prob159", "10teams"):
+        _run_and_check(name)
+    _lib.load().slip_hip_pool_release()
+    _run_and_check("10teams")
