@@ -1192,6 +1192,9 @@ SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int
 #ifndef SLIP_FARM_MIN_ITEMS
 #define SLIP_FARM_MIN_ITEMS 16          /* ... and shorter queues neither */
 #endif
+#ifndef SLIP_FARM_FEW_LIMBS
+#define SLIP_FARM_FEW_LIMBS 96          /* ... unless every item is at least this long (then two are enough) */
+#endif
 #ifndef SLIP_FARM_KIND2
 #define SLIP_FARM_KIND2     1
 #endif
@@ -1293,7 +1296,10 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
     volatile int32_t *sv = (volatile int32_t *)(lds + SLIP_LDS_VARS);
     /* (only a column whose turn is near: further away the worker has the time, and every helper costs its XCD an L2 write-back
      * and invalidate) */
-    if (P.farm && (kind == 1 || kind == 5 || (kind == 2 && SLIP_FARM_KIND2)) && nq >= SLIP_FARM_MIN_ITEMS && !sv[SV_ERR]) {
+    /* (a handful of items is worth opening too when each of them is huge: model6's columns have fewer than 16 rows of 200-364
+     * limbs, 100+ us per item -- 635 -> 530 ms; the stride tells whether such values exist at all, before the pivot is looked at) */
+    if (P.farm && (kind == 1 || kind == 5 || (kind == 2 && SLIP_FARM_KIND2)) && !sv[SV_ERR] &&
+        (nq >= SLIP_FARM_MIN_ITEMS || (nq >= 2 && P.xcap >= 4 * SLIP_FARM_FEW_LIMBS))) {
         /* kind 2: the rows of a committed column that still need their division (its readers wait for its stage 2).  The
          * protocol carries them and a 700-row column of the C4 window then takes 0.35 ms instead of 1.5 -- but the window as a
          * whole got slower (median 6.37 against 6.06 ms over 30 runs: every helper costs its XCD an L2 invalidate), so: off */
@@ -1301,7 +1307,7 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
         const int lr = kind == 5 ? slip_limbs(P.xrow[j].len) : slip_limbs(slip_ld_piv(P.piv.at(kind == 1 ? jn : k - 1)).len);
         /* the queue alone takes about nq * 8 lr^2 / waves cycles; the frontier moves a column every few microseconds */
         const int64_t cost = (int64_t) nq * lr * lr;
-        if (cost >= (kind == 2 ? (int64_t) SLIP_FARM_KIND2_COST : (int64_t) SLIP_FARM_MIN_COST) && (kind == 2 || kind == 5 || !P.in_factor || SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
+        if ((nq >= SLIP_FARM_MIN_ITEMS || lr >= SLIP_FARM_FEW_LIMBS) && cost >= (kind == 2 ? (int64_t) SLIP_FARM_KIND2_COST : (int64_t) SLIP_FARM_MIN_COST) && (kind == 2 || kind == 5 || !P.in_factor || SLIP_FARM_NEAR_DIV == 0 || (int64_t)(sv[SV_K] - sv[SV_F]) <= cost / ((int64_t) nw * (SLIP_FARM_NEAR_DIV ? SLIP_FARM_NEAR_DIV : 1)) + 2)) {
             /* a long queue of long updates: open it to the workers that are waiting */
             const int tid = slip_tid(), T = slip_nthreads();
             uint32_t *jb = P.jobs.at() + (int64_t) P.worker * SLIP_JOB_WORDS;
