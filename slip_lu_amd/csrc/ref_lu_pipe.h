@@ -1192,6 +1192,9 @@ SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int
 #ifndef SLIP_FARM_MIN_ITEMS
 #define SLIP_FARM_MIN_ITEMS 16          /* ... and shorter queues neither */
 #endif
+#ifndef SLIP_FARM_URGENT_DIST
+#define SLIP_FARM_URGENT_DIST 48        /* a waiting worker this close to its own turn only helps with queues the frontier waits for */
+#endif
 #ifndef SLIP_FARM_FEW_LIMBS
 #define SLIP_FARM_FEW_LIMBS 96          /* ... unless every item is at least this long (then two are enough) */
 #endif
@@ -1199,7 +1202,8 @@ SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int
 #define SLIP_FARM_KIND2     1
 #endif
 #ifndef SLIP_FARM_KIND2_COST
-#define SLIP_FARM_KIND2_COST 262144     /* items * limbs^2: only the heavy columns */
+#define SLIP_FARM_KIND2_COST 16384      /* items * limbs^2: the division queues of committed columns (their readers wait for stage 2);
+                                         * measured on the C4 window: 262144 -> 3.63 ms, 65536 -> 3.36, 16384 -> 3.31, 4096 -> 3.38, 1024 -> 3.35 */
 #endif
 #ifndef SLIP_FARM_NEAR_DIV
 #define SLIP_FARM_NEAR_DIV  1125        /* ... and only when the column's turn comes before the worker alone would be done */

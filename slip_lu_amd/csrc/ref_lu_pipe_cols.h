@@ -43,7 +43,7 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, i
             if (F >= need) { res = F; sv[SV_TMP3] = pr; break; }       /* pr = row_perm[F-1], for free */
             if (once) { res = F; break; }                               /* a look, not a wait: the caller has something to do meanwhile */
             /* nothing to do but wait: is another worker's update queue open to helpers?  (-2 - slot: the caller helps, then waits again) */
-            if (Pf) { const int h = slip_farm_peek(*Pf, st, k - F <= 48); if (h) { res = -1 - h; break; } }
+            if (Pf) { const int h = slip_farm_peek(*Pf, st, k - F <= SLIP_FARM_URGENT_DIST); if (h) { res = -1 - h; break; } }
             const int64_t stop = slip_ld_i64(&st->stop);
             if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             /* the further from its turn, the longer between polls: the frontier word is one line for the whole chip */
