@@ -1192,6 +1192,12 @@ SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int
 #ifndef SLIP_FARM_MIN_ITEMS
 #define SLIP_FARM_MIN_ITEMS 16          /* ... and shorter queues neither */
 #endif
+#ifndef SLIP_POLL_NEAR
+#define SLIP_POLL_NEAR 16               /* a worker this close to its turn polls the frontier at the short interval */
+#endif
+#ifndef SLIP_POLL_MAXREPS
+#define SLIP_POLL_MAXREPS 32            /* further away: min(distance, this) long sleeps between two polls */
+#endif
 #ifndef SLIP_FARM_URGENT_DIST
 #define SLIP_FARM_URGENT_DIST 48        /* a waiting worker this close to its own turn only helps with queues the frontier waits for */
 #endif

@@ -50,8 +50,8 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, i
             /* (the committer moves the frontier eight columns at a time: a worker within two batches of its turn polls at the short
              * interval -- a column that commits itself is on the commit chain from the moment the frontier reaches it) */
             const int dist = k - F;
-            if (dist <= 16) slip_sleep_short();
-            else { const int reps = dist < 32 ? dist : 32; for (int q = 0; q < reps; q++) slip_sleep(); }
+            if (dist <= SLIP_POLL_NEAR) slip_sleep_short();
+            else { const int reps = dist < SLIP_POLL_MAXREPS ? dist : SLIP_POLL_MAXREPS; for (int q = 0; q < reps; q++) slip_sleep(); }
             if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 1; st->dbg_k = k; st->dbg_a = need; st->dbg_b = F; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
         }
         sv[SV_TMP2] = res;
