@@ -1215,7 +1215,12 @@ SLIP_DEVN int slip_tol_compare_out(uint64_t tol_m, int te, const dig_t *num, int
 #define SLIP_FARM_NEAR_DIV  1125        /* ... and only when the column's turn comes before the worker alone would be done */
 #endif
 #ifndef SLIP_FARM_MAX_HELPERS
-#define SLIP_FARM_MAX_HELPERS 12         /* every helper costs its XCD an L2 invalidate and a write-back */
+#define SLIP_FARM_MAX_HELPERS 24         /* every helper costs its XCD an L2 invalidate and a write-back */
+#endif
+#ifndef SLIP_FARM_REMOTE_MAX
+#define SLIP_FARM_REMOTE_MAX 4           /* helpers from other dies join only while fewer than this many are inside; the owner's die up to MAX_HELPERS.
+                                         * C4 window, (remote, max): (12, 12) 3.40 ms, (0, 12) 3.40, (4, 12) 3.15, (4, 24) 3.05, (2, 24) 3.10, (6, 24) 3.14,
+                                         * (4, 32) 3.07, (8, 32) 3.10; (0, x) costs model6 10 %: a few remote helpers are better than none */
 #endif
 #ifndef SLIP_FARM_MIN_COST
 #define SLIP_FARM_MIN_COST  8192        /* items * limbs(rho)^2 below which a queue is not worth publishing */
@@ -1254,7 +1259,13 @@ SLIP_DEV int slip_farm_peek(const SlipParams &P, SlipState *st, int urgent_only 
         int h = slip_ld_i32(&st->farm_hint[(P.worker + q) & 7]);
         if (h < 0) { if (urgent_only) continue; h = -h; }
         if (h <= 0 || h - 1 == P.worker || h > P.nworkers) continue;
-        if (slip_ld_u32(P.jobs.at() + (int64_t)(h - 1) * SLIP_JOB_WORDS) & 1u) return h;
+        const uint32_t *jb_ = P.jobs.at() + (int64_t)(h - 1) * SLIP_JOB_WORDS;
+        const uint32_t gate = slip_ld_u32(jb_);
+        if (!(gate & 1u)) continue;
+        /* the items work on the OWNER's private rows, which live in the owner's XCD's L2: a helper on another die fetches and
+         * writes them across the fabric.  Helpers of the owner's die come first; others only while few are inside. */
+        if (SLIP_FARM_REMOTE_MAX < SLIP_FARM_MAX_HELPERS && slip_ld_u32(jb_ + 9) != slip_xcc_id() && (int)(gate >> 8) >= SLIP_FARM_REMOTE_MAX) continue;
+        return h;
     }
     return 0;
 }
@@ -1324,7 +1335,7 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
             for (int c = tid; c < ((kind == 1 || kind == 5) ? 2 * nq : nq); c += T) slip_st_u32(jb + 32 + c, wl[c]);
             if (tid == 0) {
                 slip_st_u32(jb + 2, (uint32_t) kind); slip_st_u32(jb + 3, (uint32_t) j); slip_st_u32(jb + 4, (uint32_t) jn); slip_st_u32(jb + 5, (uint32_t) k);
-                slip_st_u64((uint64_t *)(jb + 6), (uint64_t) m0); slip_st_u32(jb + 8, (uint32_t) nq); slip_st_u32(jb + 11, 0u); slip_st_u32(jb + 16, 0u);
+                slip_st_u64((uint64_t *)(jb + 6), (uint64_t) m0); slip_st_u32(jb + 8, (uint32_t) nq); slip_st_u32(jb + 9, slip_xcc_id()); slip_st_u32(jb + 11, 0u); slip_st_u32(jb + 16, 0u);
             }
             slip_vm_drain();
             slip_block_sync();

@@ -44,6 +44,8 @@ static inline uint32_t slip_emu_shl1(const uint64_t *o, uint32_t fill) { int l =
 #define slip_dpp_shl1(v, fill) slip_emu_shl1(emu::collective((uint64_t)(v), __LINE__), (fill))
 #define slip_readlane(v, lane) ((uint32_t) emu::shfl((uint64_t)(v), (lane), __LINE__))
 #define slip_dpp_shr1_in(v, in) slip_dpp_shr1((v), (in))
+/* which XCD (die) this workgroup runs on; 0 in the emulation */
+static inline uint32_t slip_xcc_id(void) { return 0u; }
 /* a value the caller knows to be wave-uniform, kept in the scalar unit (no-op in the emulation) */
 #define slip_uniform(v) ((uint32_t)(v))
 /* Hensel carry step on wave-uniform words: (n1:n0) = m1 + c1 + (t < c0) + (m2 << 32) */
@@ -166,6 +168,8 @@ SLIP_DEV uint32_t slip_dpp_shl1(uint32_t v, uint32_t fill)
     return (uint32_t) __builtin_amdgcn_update_dpp((int) fill, (int) v, 0x130, 0xF, 0xF, false);
 }
 SLIP_DEV uint32_t slip_readlane(uint32_t v, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) v, lane); }
+/* which XCD (die) this workgroup runs on (XCC_ID register) */
+SLIP_DEV uint32_t slip_xcc_id(void) { return (uint32_t) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu; }
 /* a value the caller knows to be wave-uniform, kept in the scalar unit */
 SLIP_DEV uint32_t slip_uniform(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
 /* Hensel carry step on wave-uniform words, in the scalar unit: (n1:n0) = m1 + c1 + (t < c0) + (m2 << 32).  Written out:
