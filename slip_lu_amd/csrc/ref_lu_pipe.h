@@ -72,6 +72,9 @@ typedef struct {
 } SlipPiv;
 
 /* mutable across launches; the words other workers poll sit in 128-byte lines of their own */
+#ifndef SLIP_FARM_HINTS
+#define SLIP_FARM_HINTS 16           /* hint slots (a power of two, at most 32: one line); 8 / 16 / 32 measured: model6 516 / 501 / 494 ms, C4 3.10 / 3.05 / 3.03, rl5934 119.3 / 120.1 / 121.7 */
+#endif
 typedef struct SlipState {
     int32_t F, Fpiv; int32_t padF[30];              /* ONE aligned 64-bit word: the commit frontier (columns < F have published
                                                        their pivot, stage 1) and, next to it, the pivot row of column F-1 */
@@ -79,7 +82,7 @@ typedef struct SlipState {
     int32_t F2; int32_t padF2[31];                  /* ready frontier: columns < F2 have published their L entries (stage 2) */
     int32_t ticket; int32_t padT[31];               /* next column ticket (monotonic across launches)                    */
     int32_t exited, padE[31];                       /* workers that have left the launch (the last one writes the summary) */
-    int32_t farm_hint[8], padH[24];                 /* +-(worker + 1) of workers whose update queue is open to helpers (slot worker % 8, last writer wins; hints; negative: the bulk of a committed column) */
+    int32_t farm_hint[32];                          /* +-(worker + 1) of workers whose update queue is open to helpers (slot worker % SLIP_FARM_HINTS, last writer wins; hints; negative: the bulk of a committed column) */
     int32_t committer_up, committer_where, padC[30];                 /* the committer workgroup of this launch is running (workers export packages only after they have seen it) */
     int32_t dbg_who, dbg_k, dbg_a, dbg_b;           /* which wait ran into the spin limit (diagnostic) */
     int32_t k_next, status, status_k, solve_next;
@@ -1255,8 +1258,8 @@ SLIP_DEV int slip_farm_items(const SlipParams &P, uint32_t *jb, int kind, int j,
 SLIP_DEV int slip_farm_peek(const SlipParams &P, SlipState *st, int urgent_only = 0)
 {
     if (!P.farm) return 0;
-    for (int q = 0; q < 8; q++) {
-        int h = slip_ld_i32(&st->farm_hint[(P.worker + q) & 7]);
+    for (int q = 0; q < SLIP_FARM_HINTS; q++) {
+        int h = slip_ld_i32(&st->farm_hint[(P.worker + q) & (SLIP_FARM_HINTS - 1)]);
         if (h < 0) { if (urgent_only) continue; h = -h; }
         if (h <= 0 || h - 1 == P.worker || h > P.nworkers) continue;
         const uint32_t *jb_ = P.jobs.at() + (int64_t)(h - 1) * SLIP_JOB_WORDS;
@@ -1339,14 +1342,14 @@ SLIP_DEV void slip_drain(const SlipParams &P, uint32_t *lds, int kind, int j, in
             }
             slip_vm_drain();
             slip_block_sync();
-            if (tid == 0) { slip_agent_release(); slip_agent_add_i32((int32_t *) jb, 1); slip_st_i32(&P.st->farm_hint[P.worker & 7], kind != 2 ? P.worker + 1 : -(P.worker + 1)); slip_agent_add_u64(&P.st->c_farm, 1ull); }
+            if (tid == 0) { slip_agent_release(); slip_agent_add_i32((int32_t *) jb, 1); slip_st_i32(&P.st->farm_hint[P.worker & (SLIP_FARM_HINTS - 1)], kind != 2 ? P.worker + 1 : -(P.worker + 1)); slip_agent_add_u64(&P.st->c_farm, 1ull); }
             const int e = slip_farm_items(P, jb, kind, j, jn, k, m0, nq, wl, b0, b1, b2);
             if (e && lane == 0) sv[SV_ERR] = e;
             slip_vm_drain();
             slip_block_sync();
             if (tid == 0) {
                 slip_agent_add_i32((int32_t *) jb, -1);                          /* closed: nobody new gets in */
-                { const int hh = slip_ld_i32(&P.st->farm_hint[P.worker & 7]); if (hh == P.worker + 1 || hh == -(P.worker + 1)) slip_st_i32(&P.st->farm_hint[P.worker & 7], 0); }
+                { const int hh = slip_ld_i32(&P.st->farm_hint[P.worker & (SLIP_FARM_HINTS - 1)]); if (hh == P.worker + 1 || hh == -(P.worker + 1)) slip_st_i32(&P.st->farm_hint[P.worker & (SLIP_FARM_HINTS - 1)], 0); }
                 unsigned long long spins = 0;
                 while ((slip_agent_add_i32((int32_t *) jb, 0) >> 8) != 0) { slip_sleep_short(); if (++spins > SLIP_SPIN_LIMIT) { sv[SV_ERR] = SLIPDEV_INTERNAL; P.st->dbg_who = 5; P.st->dbg_k = sv[SV_K]; P.st->dbg_a = slip_agent_add_i32((int32_t *) jb, 0); break; } }
                 const int he = (int) slip_ld_u32(jb + 11);

@@ -907,7 +907,7 @@ extern "C" int slip_emu_corrupt_entry(slip_hip_factor *f, int isU, long long t, 
 static int launch_columns(slip_hip_factor *f, hipStream_t stream)
 {
     f->P.k0 = f->hs.F; f->P.t0 = f->hs.ticket;
-    f->hs.stop = INT64_MAX; f->hs.exited = 0; for (int q_ = 0; q_ < 8; q_++) f->hs.farm_hint[q_] = 0; f->hs.dbg_who = 0; f->hs.committer_up = 0; f->hs.committer_where = 0;
+    f->hs.stop = INT64_MAX; f->hs.exited = 0; for (int q_ = 0; q_ < 32; q_++) f->hs.farm_hint[q_] = 0; f->hs.dbg_who = 0; f->hs.committer_up = 0; f->hs.committer_where = 0;
     f->P.st = f->ds; f->P.in_factor = 1;
     { const int e = upload_state(f, stream); if (e) return e; }
     /* no more workers than columns left */
@@ -1210,7 +1210,7 @@ static int launch_solve(slip_hip_factor *f, const SlipSolveArgs &A, int32_t *rhs
     f->P.t0 = f->hs.ticket;
     f->hs.stop = INT64_MAX; f->hs.exited = 0;
     f->P.farm = 0; f->P.committer = 0; f->P.st = f->ds; f->P.in_factor = 0;
-    for (int q_ = 0; q_ < 8; q_++) f->hs.farm_hint[q_] = 0;
+    for (int q_ = 0; q_ < 32; q_++) f->hs.farm_hint[q_] = 0;
     { const int e = upload_state(f, stream); if (e) return e; }
     /* one workgroup per right-hand side in flight; with fewer right-hand sides than workgroups, up to SLIP_SOLVE_HELPERS more
      * that only help with the long update queues (ref_lu_pipe_cols.h: slip_solve_worker) */
