@@ -1255,22 +1255,50 @@ SLIP_DEV int slip_farm_items(const SlipParams &P, uint32_t *jb, int kind, int j,
 /* thread 0 of a waiting worker: is there a job to help with?  returns slot + 1, or 0 */
 /* urgent_only: the caller's own turn is near -- it only helps with queues the frontier waits for (kind 1: the hint is
  * positive), not with the bulk of committed columns (kind 2: negative) */
+/* The hint words are ONE line: they are read in one round of loads (one after the other, each with its own wait, they were
+ * most of a waiting worker's poll iteration: 8-16 dependent L2 round trips, 11 us from a commit to the waiting worker seeing
+ * it).  hv[]: the line as 64-bit words (slip_farm_hints_load); the slots are walked from the worker's own on, so that the
+ * helpers of several open queues spread. */
+struct SlipHints { uint64_t w[SLIP_FARM_HINTS / 2]; };
+SLIP_DEV SlipHints slip_farm_hints_load(const SlipState *st)
+{
+    SlipHints H;
+#pragma unroll
+    for (int q = 0; q < SLIP_FARM_HINTS / 2; q++) H.w[q] = slip_ld_u64((const uint64_t *) &st->farm_hint[2 * q]);
+    return H;
+}
+SLIP_DEV int slip_farm_peek_loaded(const SlipParams &P, const SlipHints &H, int urgent_only)
+{
+    if (!P.farm) return 0;
+    uint64_t any = 0;
+#pragma unroll
+    for (int q = 0; q < SLIP_FARM_HINTS / 2; q++) any |= H.w[q];
+    if (!any) return 0;                                   /* (the usual case: nothing is open) */
+    const int start = P.worker & (SLIP_FARM_HINTS - 1);
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+        for (int q = 0; q < SLIP_FARM_HINTS; q++) {
+            if ((pass == 0) != (q >= start)) continue;
+            int h = (int)(int32_t)(uint32_t)(H.w[q >> 1] >> (32 * (q & 1)));
+            if (h < 0) { if (urgent_only) continue; h = -h; }
+            if (h <= 0 || h - 1 == P.worker || h > P.nworkers) continue;
+            const uint32_t *jb_ = P.jobs.at() + (int64_t)(h - 1) * SLIP_JOB_WORDS;
+            const uint32_t gate = slip_ld_u32(jb_);
+            if (!(gate & 1u)) continue;
+            /* the items work on the OWNER's private rows, which live in the owner's XCD's L2: a helper on another die fetches and
+             * writes them across the fabric.  Helpers of the owner's die come first; others only while few are inside. */
+            if (SLIP_FARM_REMOTE_MAX < SLIP_FARM_MAX_HELPERS && slip_ld_u32(jb_ + 9) != slip_xcc_id() && (int)(gate >> 8) >= SLIP_FARM_REMOTE_MAX) continue;
+            return h;
+        }
+    }
+    return 0;
+}
 SLIP_DEV int slip_farm_peek(const SlipParams &P, SlipState *st, int urgent_only = 0)
 {
     if (!P.farm) return 0;
-    for (int q = 0; q < SLIP_FARM_HINTS; q++) {
-        int h = slip_ld_i32(&st->farm_hint[(P.worker + q) & (SLIP_FARM_HINTS - 1)]);
-        if (h < 0) { if (urgent_only) continue; h = -h; }
-        if (h <= 0 || h - 1 == P.worker || h > P.nworkers) continue;
-        const uint32_t *jb_ = P.jobs.at() + (int64_t)(h - 1) * SLIP_JOB_WORDS;
-        const uint32_t gate = slip_ld_u32(jb_);
-        if (!(gate & 1u)) continue;
-        /* the items work on the OWNER's private rows, which live in the owner's XCD's L2: a helper on another die fetches and
-         * writes them across the fabric.  Helpers of the owner's die come first; others only while few are inside. */
-        if (SLIP_FARM_REMOTE_MAX < SLIP_FARM_MAX_HELPERS && slip_ld_u32(jb_ + 9) != slip_xcc_id() && (int)(gate >> 8) >= SLIP_FARM_REMOTE_MAX) continue;
-        return h;
-    }
-    return 0;
+    const SlipHints H = slip_farm_hints_load(st);
+    return slip_farm_peek_loaded(P, H, urgent_only);
 }
 
 /* all threads of a waiting worker: help with the job in `slot` */

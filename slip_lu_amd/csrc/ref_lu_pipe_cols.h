@@ -38,13 +38,18 @@ SLIP_DEV int slip_wait_frontier(SlipState *st, uint32_t *lds, int need, int k, i
         int res;
         unsigned long long spins = 0;
         for (;;) {
+            /* ONE round of loads per look: the frontier word, the stop word and the line of hints go out together (each with a wait
+             * of its own they made a look 10+ us long, and that is what stands between a commit and the next column seeing it) */
             int pr;
+            const bool hints = !once && Pf && Pf->farm;
+            SlipHints H;
+            if (hints) H = slip_farm_hints_load(st);
+            const int64_t stop = slip_ld_i64(&st->stop);
             const int F = slip_ld_frontier(st, &pr);
             if (F >= need) { res = F; sv[SV_TMP3] = pr; break; }       /* pr = row_perm[F-1], for free */
             if (once) { res = F; break; }                               /* a look, not a wait: the caller has something to do meanwhile */
             /* nothing to do but wait: is another worker's update queue open to helpers?  (-2 - slot: the caller helps, then waits again) */
-            if (Pf) { const int h = slip_farm_peek(*Pf, st, k - F <= SLIP_FARM_URGENT_DIST); if (h) { res = -1 - h; break; } }
-            const int64_t stop = slip_ld_i64(&st->stop);
+            if (hints) { const int h = slip_farm_peek_loaded(*Pf, H, k - F <= SLIP_FARM_URGENT_DIST); if (h) { res = -1 - h; break; } }
             if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             /* the further from its turn, the longer between polls: the frontier word is one line for the whole chip */
             /* (the committer moves the frontier eight columns at a time: a worker within two batches of its turn polls at the short
@@ -87,11 +92,15 @@ SLIP_DEV int slip_wait_ready(const SlipParams &P, SlipState *st, uint32_t *lds, 
         int res;
         unsigned long long spins = 0;
         for (;;) {
-            const int f2 = slip_advance_ready(P, st);
-            if (f2 >= need || slip_agent_add_i32(P.Lready.at(need - 1), 0) != 0) { res = f2; break; }
-            if ((int)(slip_ld_i64(&st->stop) & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
+            /* what this wait is for is ONE flag: it is looked at first, next to the stop word (one round of loads per look; the
+             * walk along the ready frontier -- a chain of returning atomics -- only once the flag is up: a reader of a late
+             * source stands on the commit chain while it waits here) */
+            const int rdy = slip_agent_load_i32(P.Lready.at(need - 1));
+            const int64_t stop = slip_ld_i64(&st->stop);
+            if (rdy != 0) { res = slip_advance_ready(P, st); break; }
+            if ((int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
             slip_sleep_short();
-            if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 2; st->dbg_k = sv[SV_K]; st->dbg_a = need; st->dbg_b = f2; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
+            if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 2; st->dbg_k = sv[SV_K]; st->dbg_a = need; st->dbg_b = rdy; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
         }
         sv[SV_TMP2] = res;
     }
@@ -718,12 +727,15 @@ SLIP_DEV int slip_wait_verdict(const SlipParams &P, SlipState *st, uint32_t *lds
         if (slip_tid() == 0) {
             int res; unsigned long long spins = 0;
             for (;;) {
+                /* (one round of loads per look: the hints, the stop word, the verdict) */
+                SlipHints H;
+                if (P.farm) H = slip_farm_hints_load(st);
+                const int64_t stop = slip_ld_i64(&st->stop);
                 const int v = (int) slip_ld_u32(pk + SLIP_PKG_OUT), mine_ = (sv[SV_PKGVER] << 24) | (k + 1);      /* a verdict names the version it is about */
                 if (v == mine_) { res = 1; break; }
                 if (v == -mine_) { res = 0; break; }
-                const int64_t stop = slip_ld_i64(&st->stop);
                 if ((stop >> 8) < (int64_t) k || (int)(stop & 0xFF) == SLIPDEV_INTERNAL) { res = -1; break; }
-                { const int h = slip_farm_peek(P, st, 1); if (h) { res = -1 - h; break; } }
+                if (P.farm) { const int h = slip_farm_peek_loaded(P, H, 1); if (h) { res = -1 - h; break; } }
                 slip_sleep_short();
                 if (++spins > SLIP_SPIN_LIMIT) { st->dbg_who = 3; st->dbg_k = k; st->dbg_a = v; st->dbg_b = mine_; slip_raise_stop(st, 0, SLIPDEV_INTERNAL); res = -1; break; }
             }
